@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the Overcooked step, random policy.
+
+Contract (one JSON line on rank 0):
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: Overcooked cramped_room, 32768 worlds per
+GPU, horizon 400, uniform random actions (scripts/overcooked_example.py:99-116
+of the reference: `randint(high=6)` per agent per step, sampling outside the
+timed call).  A step = one `mrl_step_with_actions` launch over the rank's
+world shard, actions already resident in HBM (a pre-sampled pool, cycled).
+Worlds are independent, so ranks do not communicate inside the timed region
+(weak scaling, 32768 worlds per GPU); `--gather-obs` adds the RCCL all-gather of
+the observation shards for consumers that need the global batch on every rank.
+
+Also reported: `roofline` (achieved algorithmic HBM GB/s of the step kernel,
+timed per launch with HIP events on the launch stream) and `cpu_baseline` (the
+test-only CPU oracle in oracle/, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--worlds", type=int, default=32768, help="worlds per GPU")
+    ap.add_argument("--layout", default="cramped_room")
+    ap.add_argument("--horizon", type=int, default=400)
+    ap.add_argument("--gather-obs", action="store_true", help="all-gather observation shards every step (RCCL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--pool", type=int, default=64, help="pre-sampled action tensors cycled through")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, seconds):
+    """TEST-ONLY oracle timed as the CPU baseline (kind 'port'): same layout,
+    same action distribution, all host cores, a bounded number of world-steps."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    n = 32768
+    orc = oracle.OvercookedOracle(params, n, num_threads=cores)
+    rng = np.random.default_rng(0)
+    acts = [rng.integers(0, 6, size=(params["num_players"], n)).astype(np.int32) for _ in range(8)]
+    for i in range(2):
+        orc.step(acts[i])
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.step(acts[steps % len(acts)])
+        steps += 1
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {n} worlds of the same workload ({dt:.1f} s, OpenMP over worlds)"}
+
+
+def main():
+    args = parse()
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus and world_size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+    if args.gpus > 1 and world_size == 1:
+        raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N")
+
+    import torch.distributed as dist
+    from madrona_rl_envs_playground_amd import layouts
+    from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
+
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    params = layouts.get_base_layout_params(args.layout, args.horizon)
+    P, n = params["num_players"], args.worlds
+    sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, **params)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(args.pool)]
+    obs = sim.observation_world_major_tensor().to_torch()
+    gathered = None
+    if args.gather_obs and world_size > 1:
+        gathered = torch.empty((world_size,) + tuple(obs.shape), dtype=obs.dtype, device=obs.device)
+
+    def one_step(i):
+        sim.step_with_actions(pool[i % args.pool])
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, obs)
+
+    def fence():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-launch kernel time: HIP events on the launch stream around each launch
+    k_launch = min(args.steps, 500)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(k_launch)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(k_launch)]
+    torch.cuda.synchronize()
+    for i in range(k_launch):
+        starts[i].record()
+        sim.step_with_actions(pool[i % args.pool])
+        stops[i].record()
+    torch.cuda.synchronize()
+    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        bytes_per_launch = sim.bytes_per_world_step * n
+        achieved = bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), Overcooked 32768 worlds, random policy",
+            "value": n * world_size * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"Overcooked {args.layout}, {n} worlds per GPU, horizon {args.horizon}, "
+                                   f"uniform random actions (pre-sampled pool of {args.pool}, resident in HBM)",
+                       "worlds_per_gpu": n, "obs_gather": bool(gathered is not None)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": sim.kernel_name, "kernel_us_avg": kernel_ms_avg * 1e3,
+                         "kernel_us_median": kernel_ms[len(kernel_ms) // 2] * 1e3,
+                         "bytes_per_launch": bytes_per_launch, "launches_timed": k_launch},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

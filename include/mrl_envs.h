@@ -1,0 +1,250 @@
+/*
+ * mrl_envs.h -- C ABI of the MI355X-native batched RL-environment step engine.
+ *
+ * One shared library (libmrl_envs.so, built by hipcc for gfx950) replaces, for
+ * the step hot path only, what the reference exposes through its nanobind
+ * modules.  Every entry point cites the reference interface it stands in for
+ * (paths under /root/reference).  Plain C types only: no torch, no C++ classes.
+ *
+ *   reference                                         this ABI
+ *   ------------------------------------------------  ---------------------------
+ *   OvercookedSimulator.__init__                      mrl_overcooked_create
+ *     src/overcooked_env/bindings.cpp:14-71,
+ *     Manager::Impl::init mgr.cpp:138-188
+ *   HanabiSimulator.__init__                          mrl_hanabi_create
+ *     src/hanabi_env/bindings.cpp:10-36, mgr.cpp:144-166
+ *   CartpoleSimulator.__init__                        mrl_cartpole_create
+ *     src/cartpole_env/bindings.cpp:11-24, mgr.cpp:138-163
+ *   Manager::step (all three)                         mrl_step
+ *     src/overcooked_env/mgr.cpp:196-199,
+ *     src/hanabi_env/mgr.cpp:174-177, src/cartpole_env/mgr.cpp:169-172
+ *   Manager::*Tensor()  -> madrona::py::Tensor        mrl_tensor(slot)
+ *     src/overcooked_env/mgr.cpp:201-259,
+ *     src/hanabi_env/mgr.cpp:179-232, src/cartpole_env/mgr.cpp:174-202
+ *   Manager::~Manager                                 mrl_destroy
+ *   FATAL()/abort on error (mgr.cpp:177)              return code + mrl_last_error
+ *
+ * Ownership: the simulator owns every buffer it exports for its whole
+ * lifetime (the reference's Manager owns its export buffers the same way,
+ * mgr.hpp:63); mrl_tensor hands out device pointers that never move.  The
+ * caller writes actions in place into the ACTION tensor before mrl_step and
+ * reads results in place after it, exactly as the reference's Python wrappers
+ * do (envs/overcooked_env.py:104-113, pantheonrl_extension/vectorenv.py:306-329).
+ *
+ * Streams: mrl_step only enqueues work on the HIP stream it is given (NULL =
+ * the default stream) and never synchronises the host; ordering with the
+ * caller's own work on that stream is the stream's.  A handle is bound to one
+ * device and is not thread-safe (neither is the reference's Manager).
+ *
+ * New functionality with no reference counterpart (the reference is
+ * single-device): the two-phase step and the episode
+ * base used to keep episode numbering identical when worlds are sharded over
+ * several GPUs.
+ */
+#ifndef MRL_ENVS_H
+#define MRL_ENVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRL_ABI_VERSION 1
+
+/* return codes */
+enum {
+    MRL_OK = 0,
+    MRL_ERR_INVALID = 1, /* bad argument / unsupported configuration          */
+    MRL_ERR_DEVICE = 2,  /* no usable gfx950 device, or a HIP call failed      */
+    MRL_ERR_SLOT = 3     /* tensor slot not exported by this game             */
+};
+
+/* element types of exported tensors (madrona::py::Tensor::ElementType subset) */
+enum { MRL_INT8 = 0, MRL_UINT8 = 1, MRL_INT32 = 2, MRL_FLOAT32 = 3, MRL_UINT32 = 4 };
+
+enum { MRL_GAME_OVERCOOKED = 1, MRL_GAME_HANABI = 2, MRL_GAME_CARTPOLE = 3 };
+
+typedef struct mrl_sim mrl_sim;
+
+#define MRL_MAX_DIMS 6
+typedef struct mrl_tensor_desc {
+    void *data;                    /* device pointer (HBM), valid until mrl_destroy   */
+    int32_t dtype;                 /* MRL_INT8 ...                                    */
+    int32_t ndim;
+    int64_t shape[MRL_MAX_DIMS];
+    int64_t strides[MRL_MAX_DIMS]; /* in elements; exported views may be strided      */
+    int32_t device;                /* HIP device ordinal                              */
+    int32_t reserved;
+} mrl_tensor_desc;
+
+/* ------------------------------------------------------------------ */
+/* Overcooked  (reference: src/overcooked_env)                          */
+/* ------------------------------------------------------------------ */
+
+/* Mirrors Manager::Config (mgr.hpp:16-35): the Python layout transform
+ * (envs/overcooked_env.py:261-371) produces exactly these fields.  Limits are
+ * the reference's: height*width <= 255 (WorldState.size is uint8, sim.hpp:86),
+ * num_players <= 64 (sim.hpp:14); reward / recipe entries are stored as uint8
+ * (sim.hpp:95-99). */
+typedef struct mrl_overcooked_config {
+    int64_t height, width, num_players;
+    int64_t placement_in_pot_rew, dish_pickup_rew, soup_pickup_rew;
+    int64_t horizon;
+    const int64_t *terrain;        /* height*width, row-major, TerrainT values 0..6 */
+    const int64_t *start_player_x; /* num_players                                   */
+    const int64_t *start_player_y; /* num_players                                   */
+    const int64_t *recipe_values;  /* 16, index 4*onions + tomatoes                 */
+    const int64_t *recipe_times;   /* 16                                            */
+} mrl_overcooked_config;
+
+/* Tensor slots = ExportID (sim.hpp:23-37) + this engine's world-major views.
+ * P players, N worlds, C = height*width, F = 5P + 16.
+ *   DONE              int32 (N)
+ *   ACTIVE_AGENT      int32 (P, N)            all ones (sim.cpp:619)
+ *   ACTION            int32 (P, N, 1)         written by the caller
+ *   OBSERVATION       int8  (P*C, N, F)       strided view of OBS_WORLD_MAJOR; row id
+ *                                             p*C + cell like LocationXID (sim.cpp:633).
+ *                                             The reference pads rows to 336 bytes
+ *                                             (sim.hpp:125-127) and callers slice [:F];
+ *                                             here the last dimension is F already.
+ *   ACTION_MASK       int32 (P, N, 6)         all ones (sim.cpp:616-618)
+ *   REWARD            int32 (P, N)
+ *   WORLD_ID          int32 (P, N)            [p, n] = n
+ *   AGENT_ID          int32 (P, N)            [p, n] = p
+ *   LOCATION_WORLD_ID int32 (P*C, N)          [r, n] = n
+ *   LOCATION_ID       int32 (P*C, N)          [r, n] = r
+ *   OBS_WORLD_MAJOR   int8  (N, P, H, W, F)   contiguous; what the kernel writes
+ *   STATE_PLAYERS     uint8 (N, P, 8)         pos, orientation, pad, pad, held{name,on,tom,tick}
+ *   STATE_OBJECTS     uint8 (N, C, 4)         name, onions, tomatoes, cooking_tick
+ *   STATE_TIMESTEP    int32 (N)
+ */
+enum {
+    MRL_OVERCOOKED_DONE = 0,
+    MRL_OVERCOOKED_ACTIVE_AGENT = 1,
+    MRL_OVERCOOKED_ACTION = 2,
+    MRL_OVERCOOKED_OBSERVATION = 3,
+    MRL_OVERCOOKED_ACTION_MASK = 4,
+    MRL_OVERCOOKED_REWARD = 5,
+    MRL_OVERCOOKED_WORLD_ID = 6,
+    MRL_OVERCOOKED_AGENT_ID = 7,
+    MRL_OVERCOOKED_LOCATION_WORLD_ID = 8,
+    MRL_OVERCOOKED_LOCATION_ID = 9,
+    MRL_OVERCOOKED_OBS_WORLD_MAJOR = 10,
+    MRL_OVERCOOKED_STATE_PLAYERS = 11,
+    MRL_OVERCOOKED_STATE_OBJECTS = 12,
+    MRL_OVERCOOKED_STATE_TIMESTEP = 13
+};
+
+/* replaces OvercookedSimulator(exec_mode=CUDA, gpu_id, num_worlds, **layout)
+ * (bindings.cpp:14-71).  There is no CPU execution mode behind this ABI. */
+int mrl_overcooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
+
+/* ------------------------------------------------------------------ */
+/* Hanabi  (reference: src/hanabi_env; 2 players, hand of 5)            */
+/* ------------------------------------------------------------------ */
+
+typedef struct mrl_hanabi_config {
+    uint32_t colors, ranks, players, max_information_tokens, max_life_tokens;
+} mrl_hanabi_config;
+
+#define MRL_HANABI_OBS_SIZE 658   /* OBS_SIZE   sim.hpp:29 */
+#define MRL_HANABI_STATE_SIZE 783 /* STATE_SIZE sim.hpp:30 */
+#define MRL_HANABI_NUM_MOVES 20   /* NUM_MOVES  sim.hpp:19 */
+
+/* Slots = ExportID (src/hanabi_env/sim.hpp:38-49); shapes as mgr.cpp:179-232:
+ *   DONE int32 (N); ACTIVE_AGENT int32 (2,N); ACTION int32 (2,N,1);
+ *   OBSERVATION int8 (2,N,658); ACTION_MASK int32 (2,N,20); REWARD float32 (2,N);
+ *   WORLD_ID / AGENT_ID int32 (2,N); STATE int8 (2,N,783);
+ *   GAME uint8 (N, 176): the raw per-world game record (tests only; layout in
+ *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last step. */
+enum {
+    MRL_HANABI_DONE = 0,
+    MRL_HANABI_ACTIVE_AGENT = 1,
+    MRL_HANABI_ACTION = 2,
+    MRL_HANABI_OBSERVATION = 3,
+    MRL_HANABI_ACTION_MASK = 4,
+    MRL_HANABI_REWARD = 5,
+    MRL_HANABI_WORLD_ID = 6,
+    MRL_HANABI_AGENT_ID = 7,
+    MRL_HANABI_STATE = 8,
+    MRL_HANABI_GAME = 9,
+    MRL_HANABI_RESET_COUNT = 10
+};
+
+int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
+
+/* ------------------------------------------------------------------ */
+/* Cartpole  (reference: src/cartpole_env)                              */
+/* ------------------------------------------------------------------ */
+
+/* Slots = ExportID (src/cartpole_env/sim.hpp:17-24); shapes as mgr.cpp:174-202:
+ *   RESET int32 (N,1); ACTION int32 (N,1); STATE float32 (N,4) (the Python
+ *   binding calls it observation_tensor, bindings.cpp:28); REWARD float32 (N,1);
+ *   WORLD_ID int32 (N,1); RESET_COUNT uint32 (1). */
+enum {
+    MRL_CARTPOLE_RESET = 0,
+    MRL_CARTPOLE_ACTION = 1,
+    MRL_CARTPOLE_STATE = 2,
+    MRL_CARTPOLE_REWARD = 3,
+    MRL_CARTPOLE_WORLD_ID = 4,
+    MRL_CARTPOLE_RESET_COUNT = 5
+};
+
+int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
+
+/* ------------------------------------------------------------------ */
+/* Common                                                               */
+/* ------------------------------------------------------------------ */
+
+/* One environment step for every world: replaces Manager::step. */
+int mrl_step(mrl_sim *sim, void *hip_stream);
+
+/* Same step, but actions are read from caller memory instead of the ACTION
+ * tensor (same dtype/shape/layout, device pointer).  Saves the copy the
+ * reference wrappers make (static_actions.copy_, envs/overcooked_env.py:107). */
+int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream);
+
+/* Two-phase step for world batches sharded over several GPUs (Hanabi and
+ * Cartpole draw each new episode's seed from one global counter,
+ * src/hanabi_env/sim.cpp:449-451, src/cartpole_env/sim.cpp:51-53):
+ *   phase 1 = transition + termination test, leaves the number of finishing
+ *             worlds in RESET_COUNT;
+ *   phase 2 = re-seed and reset the finishing worlds, taking episode indices
+ *             episode_base, episode_base+1, ... in ascending world order.
+ * episode_base_dev is a device pointer to one uint32 (the caller computes it
+ * from the gathered RESET_COUNTs of the lower ranks without a host sync);
+ * NULL means "use and advance the simulator's own counter" (single GPU).
+ * mrl_step == phase 1 + phase 2(NULL).  Overcooked has no episode counter:
+ * phase 1 is the whole step and phase 2 is a no-op. */
+int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream);
+int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_stream);
+
+/* Sets the simulator's own episode counter (next index handed out). Sharded
+ * runs call it once after create with the global world offset semantics the
+ * caller wants; it does not touch world state. */
+int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream);
+
+/* Re-initialises world i of this shard as global world (world_offset + i) of a
+ * num_worlds_total batch: episode index world_offset + i, counter starts at
+ * num_worlds_total -- what a single simulator of the whole batch would hold
+ * after construction.  No-op for Overcooked (its initial state is not seeded). */
+int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_total, void *hip_stream);
+
+int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out);
+int mrl_game(const mrl_sim *sim);
+uint32_t mrl_num_worlds(const mrl_sim *sim);
+/* name of the dominant kernel of this simulator's step, as rocprofv3 prints it */
+const char *mrl_kernel_name(const mrl_sim *sim);
+/* algorithmic HBM bytes one step moves per world */
+uint64_t mrl_bytes_per_world_step(const mrl_sim *sim);
+void mrl_destroy(mrl_sim *sim);
+
+/* message of the last failing call on this thread ("" if none) */
+const char *mrl_last_error(void);
+int mrl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRL_ENVS_H */

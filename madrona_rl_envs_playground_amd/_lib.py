@@ -1,0 +1,117 @@
+"""ctypes binding of libmrl_envs.so -- the C ABI declared in include/mrl_envs.h.
+
+There is no fallback: if the library is missing or cannot be loaded the import
+of any simulator raises.  ``build()`` compiles it with hipcc for gfx950
+(cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+# torch first: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so).
+# If libmrl_envs.so pulled in /opt/rocm's copy before torch is imported, the
+# process would hold two runtimes and torch's would find no GPU.
+import torch  # noqa: F401
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmrl_envs.so")
+CSRC = os.path.join(_PKG, "csrc")
+HEADER = os.path.join(os.path.dirname(_PKG), "include", "mrl_envs.h")
+
+MRL_OK, MRL_ERR_INVALID, MRL_ERR_DEVICE, MRL_ERR_SLOT = 0, 1, 2, 3
+MRL_INT8, MRL_UINT8, MRL_INT32, MRL_FLOAT32, MRL_UINT32 = 0, 1, 2, 3, 4
+MAX_DIMS = 6
+
+# every symbol include/mrl_envs.h declares
+SYMBOLS = [
+    "mrl_overcooked_create", "mrl_hanabi_create", "mrl_cartpole_create", "mrl_step", "mrl_step_with_actions",
+    "mrl_step_phase1", "mrl_step_phase2", "mrl_set_episode_counter", "mrl_reseed_shard", "mrl_tensor", "mrl_game",
+    "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
+    "mrl_abi_version",
+]
+
+
+class TensorDesc(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * MAX_DIMS), ("strides", ctypes.c_int64 * MAX_DIMS),
+                ("device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class OvercookedConfig(ctypes.Structure):
+    _fields_ = [("height", ctypes.c_int64), ("width", ctypes.c_int64), ("num_players", ctypes.c_int64),
+                ("placement_in_pot_rew", ctypes.c_int64), ("dish_pickup_rew", ctypes.c_int64),
+                ("soup_pickup_rew", ctypes.c_int64), ("horizon", ctypes.c_int64),
+                ("terrain", ctypes.POINTER(ctypes.c_int64)), ("start_player_x", ctypes.POINTER(ctypes.c_int64)),
+                ("start_player_y", ctypes.POINTER(ctypes.c_int64)), ("recipe_values", ctypes.POINTER(ctypes.c_int64)),
+                ("recipe_times", ctypes.POINTER(ctypes.c_int64))]
+
+
+class HanabiConfig(ctypes.Structure):
+    _fields_ = [("colors", ctypes.c_uint32), ("ranks", ctypes.c_uint32), ("players", ctypes.c_uint32),
+                ("max_information_tokens", ctypes.c_uint32), ("max_life_tokens", ctypes.c_uint32)]
+
+
+class MrlError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into libmrl_envs.so for gfx950 (needs hipcc, no GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    proc = subprocess.run(["make", "-C", CSRC, "-B"], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout + proc.stderr)
+    if proc.returncode != 0:
+        raise MrlError("building libmrl_envs.so failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MrlError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step kernels.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
+    L.mrl_overcooked_create.argtypes = [ctypes.POINTER(OvercookedConfig), i32, u32, ctypes.POINTER(vp)]
+    L.mrl_hanabi_create.argtypes = [ctypes.POINTER(HanabiConfig), i32, u32, ctypes.POINTER(vp)]
+    L.mrl_cartpole_create.argtypes = [i32, u32, ctypes.POINTER(vp)]
+    L.mrl_step.argtypes = [vp, vp]
+    L.mrl_step_with_actions.argtypes = [vp, vp, vp]
+    L.mrl_step_phase1.argtypes = [vp, vp, vp]
+    L.mrl_step_phase2.argtypes = [vp, vp, vp]
+    L.mrl_set_episode_counter.argtypes = [vp, u32, vp]
+    L.mrl_reseed_shard.argtypes = [vp, u32, u32, vp]
+    L.mrl_tensor.argtypes = [vp, i32, ctypes.POINTER(TensorDesc)]
+    L.mrl_game.argtypes = [vp]
+    L.mrl_num_worlds.argtypes = [vp]
+    L.mrl_num_worlds.restype = u32
+    L.mrl_kernel_name.argtypes = [vp]
+    L.mrl_kernel_name.restype = ctypes.c_char_p
+    L.mrl_bytes_per_world_step.argtypes = [vp]
+    L.mrl_bytes_per_world_step.restype = ctypes.c_uint64
+    L.mrl_destroy.argtypes = [vp]
+    L.mrl_destroy.restype = None
+    L.mrl_last_error.restype = ctypes.c_char_p
+    L.mrl_abi_version.restype = i32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != MRL_OK:
+        msg = lib().mrl_last_error().decode() or f"error code {rc}"
+        raise MrlError(msg)
+
+
+def i64_array(values):
+    arr = (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+    return arr

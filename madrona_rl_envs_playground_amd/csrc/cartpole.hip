@@ -1,0 +1,247 @@
+// Cartpole world step for gfx950: one lane per world (the state is four floats,
+// so a wave moves 64 worlds with one 16-byte load and one 16-byte store per lane).
+//
+// Semantics: /root/reference/src/cartpole_env/sim.cpp:9-21 (constants are double
+// literals, so most intermediates are double), :68-84 (explicit Euler step),
+// :86-96 (termination), :48-66 (reset from the episode-seeded generator,
+// rng.hpp:5-40).  This file is compiled with -ffp-contract=off: the reference's
+// CPU executor rounds every product and sum separately.
+//
+// The reference hands out episode indices from one global atomic in whatever
+// order worlds happen to reset (sim.cpp:51-53).  Here the order is fixed:
+// ascending world index within a step.  That needs a prefix sum over the
+// termination flags, so the step is two launches:
+//   mrl_cartpole_step : dynamics + done flag + per-workgroup reset counts
+//   mrl_cartpole_reset: exclusive prefix over the counts, re-seed finished worlds
+// HBM traffic per world-step: action 4 + state r/w 32 + reward 4 + done 4 = 44 B.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+#define GRAVITY 9.8
+#define MASSCART 1.0
+#define MASSPOLE 0.1
+#define TOTAL_MASS (MASSPOLE + MASSCART)
+#define LENGTH 0.5
+#define POLEMASS_LENGTH (MASSPOLE * LENGTH)
+#define FORCE_MAG 10
+#define TAU 0.02
+#define X_THRESHOLD 2.4
+#define PI_D 3.141592653589793238463
+#define THETA_THRESHOLD (12 * 2 * PI_D / 360)
+
+__device__ __forceinline__ uint32_t seed_of(uint32_t episode)
+{
+    // rng.hpp:7-26
+    uint32_t v0 = episode, v1 = 0, sum = 0;
+#pragma unroll
+    for (int round = 0; round < 8; round++) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+__device__ __forceinline__ float next_uniform(uint32_t &g)
+{
+    // rng.hpp:28-36
+    g = 1664525u * g + 1013904223u;
+    return (float)(g & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+__device__ __forceinline__ float4 fresh_state(uint32_t episode)
+{
+    // sim.cpp:55-65
+    uint32_t g = seed_of(episode);
+    const float lo = -0.05f, span = 0.05f - (-0.05f);
+    float4 s;
+    s.x = lo + next_uniform(g) * span;
+    s.y = lo + next_uniform(g) * span;
+    s.z = lo + next_uniform(g) * span;
+    s.w = lo + next_uniform(g) * span;
+    return s;
+}
+
+// counts the set flags of a workgroup; returns this thread's exclusive rank
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint32_t &block_total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votes = __ballot(flag);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(votes);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kBlock / 64; w++) {
+        const uint32_t c = s_wave[w];
+        before += w < wave ? c : 0;
+        total += c;
+    }
+    block_total = total;
+    return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, const int32_t *__restrict__ action,
+                                                            float4 *__restrict__ state, float *__restrict__ reward,
+                                                            int32_t *__restrict__ done, uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool over = false;
+    if (i < n) {
+        const float4 s = state[i];
+        float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
+        // sim.cpp:70-83; expression types as written there
+        const float force = (action[i] == 1 ? FORCE_MAG : -FORCE_MAG);
+        const float costheta = cosf(theta);
+        const float sintheta = sinf(theta);
+        const float temp = (force + POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / TOTAL_MASS;
+        const float thetaacc =
+            (GRAVITY * sintheta - costheta * temp) / (LENGTH * (4.0 / 3.0 - MASSPOLE * costheta * costheta / TOTAL_MASS));
+        const float xacc = temp - POLEMASS_LENGTH * thetaacc * costheta / TOTAL_MASS;
+        x = x + TAU * x_dot;
+        x_dot = x_dot + TAU * xacc;
+        theta = theta + TAU * theta_dot;
+        theta_dot = theta_dot + TAU * thetaacc;
+        // sim.cpp:88-91
+        over = x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
+        state[i] = make_float4(x, x_dot, theta, theta_dot);
+        reward[i] = 1.f;
+        done[i] = over ? 1 : 0;
+    }
+    uint32_t total;
+    (void)block_rank(over, s_wave, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, const int32_t *__restrict__ done,
+                                                             float4 *__restrict__ state,
+                                                             const uint32_t *__restrict__ block_counts,
+                                                             const uint32_t *__restrict__ episode_base,
+                                                             uint32_t *__restrict__ next_counter,
+                                                             uint32_t *__restrict__ reset_count)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_part[kBlock / 64];
+    // exclusive prefix of the counts of the workgroups before this one
+    uint32_t mine = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) mine += block_counts[b];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    uint32_t prefix = 0;
+    for (uint32_t w = 0; w < kBlock / 64; w++) prefix += s_part[w];
+
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool over = i < n && done[i] != 0;
+    uint32_t total;
+    const uint32_t rank = block_rank(over, s_wave, total);
+    const uint32_t base = *episode_base;
+    if (over) state[i] = fresh_state(base + prefix + rank);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *reset_count = prefix + total;
+        *next_counter = base + prefix + total;
+    }
+}
+
+__global__ void mrl_cartpole_init(uint32_t n, uint32_t world_offset, float4 *state, int32_t *world_id)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        state[i] = fresh_state(world_offset + i);  // the constructor gives world i episode i (sim.cpp:141)
+        world_id[i] = (int32_t)i;
+    }
+}
+
+struct CartpoleSim final : mrl_sim {
+    uint32_t grid = 0;
+    int32_t *action = nullptr, *done = nullptr, *world_id = nullptr;
+    float4 *state = nullptr;
+    float *reward = nullptr;
+    uint32_t *block_counts = nullptr;
+    uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
+    uint32_t *reset_count = nullptr;
+    uint32_t parity = 0;
+
+    void phase1(const int32_t *actions, hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds,
+                           actions ? actions : action, state, reward, done, block_counts);
+        MRL_HIP(hipGetLastError());
+    }
+
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
+        hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, done, state,
+                           block_counts, base, counter + (parity ^ 1u), reset_count);
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
+
+    void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
+    {
+        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        MRL_HIP(hipStreamSynchronize(stream));
+    }
+
+    void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl_cartpole_init, dim3(grid), dim3(kBlock), 0, stream, num_worlds, world_offset, state,
+                           world_id);
+        MRL_HIP(hipGetLastError());
+        MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
+        MRL_HIP(hipMemsetAsync(reward, 0, sizeof(float) * num_worlds, stream));
+        set_episode_counter(num_worlds_total, stream);
+    }
+
+    bool tensor(int slot, mrl_tensor_desc *out) override
+    {
+        const int64_t N = num_worlds;
+        switch (slot) {
+        case MRL_CARTPOLE_RESET: *out = mrl::make_desc(done, MRL_INT32, device, {N, 1}); return true;
+        case MRL_CARTPOLE_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {N, 1}); return true;
+        case MRL_CARTPOLE_STATE: *out = mrl::make_desc(state, MRL_FLOAT32, device, {N, 4}); return true;
+        case MRL_CARTPOLE_REWARD: *out = mrl::make_desc(reward, MRL_FLOAT32, device, {N, 1}); return true;
+        case MRL_CARTPOLE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {N, 1}); return true;
+        case MRL_CARTPOLE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        default: return false;
+        }
+    }
+
+    const char *kernel_name() const override { return "mrl_cartpole_step"; }
+    uint64_t bytes_per_world_step() const override { return 44; }
+};
+
+}  // namespace
+
+mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
+{
+    if (num_worlds == 0) {
+        set_error("cartpole: num_worlds must be > 0");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    bind_device(gpu_id);
+    auto *sim = new CartpoleSim();
+    try {
+        sim->game = MRL_GAME_CARTPOLE;
+        sim->device = gpu_id;
+        sim->num_worlds = num_worlds;
+        sim->grid = (num_worlds + kBlock - 1) / kBlock;
+        sim->action = sim->arena.alloc<int32_t>(num_worlds);
+        sim->done = sim->arena.alloc<int32_t>(num_worlds);
+        sim->world_id = sim->arena.alloc<int32_t>(num_worlds);
+        sim->state = sim->arena.alloc<float4>(num_worlds);
+        sim->reward = sim->arena.alloc<float>(num_worlds);
+        sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        sim->counter = sim->arena.alloc<uint32_t>(2);
+        sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        sim->reseed_shard(0, num_worlds, 0);
+        MRL_HIP(hipDeviceSynchronize());
+    } catch (...) {
+        delete sim;
+        throw;
+    }
+    return sim;
+}

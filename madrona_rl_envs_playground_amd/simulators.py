@@ -1,0 +1,248 @@
+"""Python-visible simulator classes: drop-in for the reference's nanobind modules.
+
+    reference module                            class here
+    build.madrona_overcooked_example_python  -> OvercookedSimulator   (src/overcooked_env/bindings.cpp:11-84)
+    build.madrona_hanabi_example_python      -> HanabiSimulator       (src/hanabi_env/bindings.cpp:8-48)
+    build.madrona_cartpole_example_python    -> CartpoleSimulator     (src/cartpole_env/bindings.cpp:8-31)
+
+Same constructor keywords, same method names; every ``*_tensor()`` returns an
+object whose ``to_torch()`` yields a persistent zero-copy ``torch.Tensor`` on the
+simulator's GPU (the reference's ``madrona.py.Tensor.to_torch()``).  ``madrona``
+below mimics the ``<module>.madrona`` submodule the wrappers reach for
+(envs/overcooked_env.py:31).
+
+Everything is computed by libmrl_envs.so (HIP, gfx950).  ``ExecMode.CPU`` raises:
+the reference's CPU TaskGraph executor is out of scope, and a
+silent CPU path would defeat the parity tests.
+"""
+import ctypes
+import enum
+
+import torch
+
+from . import _lib
+from ._lib import MrlError  # noqa: F401  (re-export)
+
+
+class ExecMode(enum.Enum):
+    CPU = 0
+    CUDA = 1
+    HIP = 1  # alias: on this engine the GPU mode is HIP on MI355X
+
+
+class madrona:  # noqa: N801  (mirrors `<module>.madrona.ExecMode`)
+    ExecMode = ExecMode
+
+
+_TORCH_DTYPE = {
+    _lib.MRL_INT8: (torch.int8, "|i1", 1),
+    _lib.MRL_UINT8: (torch.uint8, "|u1", 1),
+    _lib.MRL_INT32: (torch.int32, "<i4", 4),
+    _lib.MRL_FLOAT32: (torch.float32, "<f4", 4),
+    _lib.MRL_UINT32: (torch.int32, "<i4", 4),  # torch has no general uint32; same bits
+}
+
+
+class _DeviceBlob:
+    """Carrier for ``__cuda_array_interface__``; keeps the simulator alive."""
+
+    def __init__(self, owner, ptr, shape, strides_bytes, typestr):
+        self._owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+            "strides": tuple(strides_bytes),
+        }
+
+
+class Tensor:
+    """What ``sim.*_tensor()`` returns (stands in for ``madrona::py::Tensor``)."""
+
+    def __init__(self, sim, slot):
+        desc = _lib.TensorDesc()
+        _lib.check(_lib.lib().mrl_tensor(sim._handle, slot, ctypes.byref(desc)))
+        self._sim = sim
+        self.ptr = desc.data
+        self.dtype_code = desc.dtype
+        self.shape = tuple(desc.shape[i] for i in range(desc.ndim))
+        self.strides = tuple(desc.strides[i] for i in range(desc.ndim))
+        self.device = desc.device
+        self._torch = None
+
+    def to_torch(self):
+        if self._torch is None:
+            dtype, typestr, size = _TORCH_DTYPE[self.dtype_code]
+            blob = _DeviceBlob(self._sim, self.ptr, self.shape, [s * size for s in self.strides], typestr)
+            t = torch.as_tensor(blob, device=torch.device("cuda", self.device))
+            if t.dtype != dtype:
+                t = t.view(dtype)
+            if t.data_ptr() != self.ptr:
+                raise MrlError("torch.as_tensor copied the exported buffer instead of aliasing it")
+            self._torch = t
+        return self._torch
+
+
+class _Simulator:
+    """Shared handle management for the three games."""
+
+    _SLOTS = {}
+
+    def __init__(self, exec_mode, gpu_id):
+        mode = getattr(exec_mode, "name", str(exec_mode))
+        if mode == "CPU" or exec_mode == 0:
+            raise NotImplementedError(
+                "ExecMode.CPU: this engine has only the HIP (MI355X) step kernels; the reference's CPU "
+                "TaskGraph executor is not reproduced (the test-only CPU oracle lives in oracle/).")
+        self._L = _lib.lib()
+        self._handle = ctypes.c_void_p()
+        self.gpu_id = int(gpu_id)
+        self._tensors = {}
+
+    # --- reference API -------------------------------------------------
+    def step(self):
+        """One environment step for all worlds, enqueued on torch's current stream
+        (Manager::step; no host synchronisation)."""
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        rc = self._L.mrl_step(self._handle, stream)
+        if rc:
+            _lib.check(rc)
+
+    # --- extensions ----------------------------------------------------
+    def step_with_actions(self, actions):
+        """Step reading actions from ``actions`` (int32, the ACTION tensor's shape,
+        contiguous, on this GPU) instead of the ACTION tensor."""
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device.index != self.gpu_id:
+            raise ValueError("actions must be a contiguous int32 tensor on the simulator's device")
+        if actions.numel() != self._action_numel:
+            raise ValueError(f"actions has {actions.numel()} elements, expected {self._action_numel}")
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        rc = self._L.mrl_step_with_actions(self._handle, actions.data_ptr(), stream)
+        if rc:
+            _lib.check(rc)
+
+    def step_phase1(self, actions=None):
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        _lib.check(self._L.mrl_step_phase1(self._handle, actions.data_ptr() if actions is not None else None, stream))
+
+    def step_phase2(self, episode_base=None):
+        """``episode_base``: 1-element int32/uint32 CUDA tensor, or None for the
+        simulator's own counter."""
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        ptr = episode_base.data_ptr() if episode_base is not None else None
+        _lib.check(self._L.mrl_step_phase2(self._handle, ptr, stream))
+
+    def reseed_shard(self, world_offset, num_worlds_total):
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        _lib.check(self._L.mrl_reseed_shard(self._handle, int(world_offset), int(num_worlds_total), stream))
+
+    def set_episode_counter(self, next_episode):
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        _lib.check(self._L.mrl_set_episode_counter(self._handle, int(next_episode), stream))
+
+    @property
+    def kernel_name(self):
+        return self._L.mrl_kernel_name(self._handle).decode()
+
+    @property
+    def bytes_per_world_step(self):
+        return int(self._L.mrl_bytes_per_world_step(self._handle))
+
+    @property
+    def num_worlds(self):
+        return int(self._L.mrl_num_worlds(self._handle))
+
+    def _tensor(self, slot):
+        if slot not in self._tensors:
+            self._tensors[slot] = Tensor(self, slot)
+        return self._tensors[slot]
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._L.mrl_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OvercookedSimulator(_Simulator):
+    """Signature of src/overcooked_env/bindings.cpp:14-71."""
+
+    def __init__(self, exec_mode, gpu_id, num_worlds, terrain, height, width, num_players, start_player_x,
+                 start_player_y, placement_in_pot_rew, dish_pickup_rew, soup_pickup_rew, recipe_values, recipe_times,
+                 horizon, debug_compile=True):
+        super().__init__(exec_mode, gpu_id)
+        if len(terrain) < height * width:
+            raise ValueError("terrain shorter than height*width")
+        if len(start_player_x) < num_players or len(start_player_y) < num_players:
+            raise ValueError("fewer start positions than players")
+        if len(recipe_values) < 16 or len(recipe_times) < 16:
+            raise ValueError("recipe tables need 16 entries")
+        keep = [_lib.i64_array(terrain), _lib.i64_array(start_player_x), _lib.i64_array(start_player_y),
+                _lib.i64_array(recipe_values), _lib.i64_array(recipe_times)]
+        cfg = _lib.OvercookedConfig(int(height), int(width), int(num_players), int(placement_in_pot_rew),
+                                    int(dish_pickup_rew), int(soup_pickup_rew), int(horizon), *keep)
+        _lib.check(self._L.mrl_overcooked_create(ctypes.byref(cfg), int(gpu_id), int(num_worlds),
+                                                 ctypes.byref(self._handle)))
+        self.num_players, self.height, self.width = int(num_players), int(height), int(width)
+        self._action_numel = int(num_players) * int(num_worlds)
+
+    def done_tensor(self): return self._tensor(0)
+    def active_agent_tensor(self): return self._tensor(1)
+    def action_tensor(self): return self._tensor(2)
+    def observation_tensor(self): return self._tensor(3)
+    def agent_state_tensor(self): return self._tensor(3)  # alias, bindings.cpp:77
+    def action_mask_tensor(self): return self._tensor(4)
+    def reward_tensor(self): return self._tensor(5)
+    def world_id_tensor(self): return self._tensor(6)
+    def agent_id_tensor(self): return self._tensor(7)
+    def location_world_id_tensor(self): return self._tensor(8)
+    def location_id_tensor(self): return self._tensor(9)
+    # world-major views of this engine (no reference counterpart)
+    def observation_world_major_tensor(self): return self._tensor(10)
+    def state_players_tensor(self): return self._tensor(11)
+    def state_objects_tensor(self): return self._tensor(12)
+    def state_timestep_tensor(self): return self._tensor(13)
+
+
+class HanabiSimulator(_Simulator):
+    """Signature of src/hanabi_env/bindings.cpp:10-36."""
+
+    def __init__(self, exec_mode, gpu_id, num_worlds, colors, ranks, players, max_information_tokens,
+                 max_life_tokens, debug_compile=True):
+        super().__init__(exec_mode, gpu_id)
+        cfg = _lib.HanabiConfig(int(colors), int(ranks), int(players), int(max_information_tokens),
+                                int(max_life_tokens))
+        _lib.check(self._L.mrl_hanabi_create(ctypes.byref(cfg), int(gpu_id), int(num_worlds),
+                                             ctypes.byref(self._handle)))
+        self._action_numel = 2 * int(num_worlds)
+
+    def done_tensor(self): return self._tensor(0)
+    def active_agent_tensor(self): return self._tensor(1)
+    def action_tensor(self): return self._tensor(2)
+    def observation_tensor(self): return self._tensor(3)
+    def action_mask_tensor(self): return self._tensor(4)
+    def reward_tensor(self): return self._tensor(5)
+    def world_id_tensor(self): return self._tensor(6)
+    def agent_id_tensor(self): return self._tensor(7)
+    def agent_state_tensor(self): return self._tensor(8)
+    def game_tensor(self): return self._tensor(9)
+    def reset_count_tensor(self): return self._tensor(10)
+
+
+class CartpoleSimulator(_Simulator):
+    """Signature of src/cartpole_env/bindings.cpp:11-24."""
+
+    def __init__(self, exec_mode, gpu_id, num_worlds, debug_compile=True):
+        super().__init__(exec_mode, gpu_id)
+        _lib.check(self._L.mrl_cartpole_create(int(gpu_id), int(num_worlds), ctypes.byref(self._handle)))
+        self._action_numel = int(num_worlds)
+
+    def reset_tensor(self): return self._tensor(0)
+    def action_tensor(self): return self._tensor(1)
+    def observation_tensor(self): return self._tensor(2)
+    def reward_tensor(self): return self._tensor(3)
+    def world_id_tensor(self): return self._tensor(4)
+    def reset_count_tensor(self): return self._tensor(5)
