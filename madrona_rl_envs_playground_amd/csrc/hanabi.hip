@@ -1,6 +1,725 @@
+// 2-player Hanabi world step for gfx950.
+//
+// Semantics: /root/reference/src/hanabi_env/sim.cpp (drawDeck :45-52, encoders
+// :54-365, legal moves :381-444, resetWorld :446-532, removeFromHand :567-594,
+// actionSystem :596-792, observationSystem :794-810, checkDone :812-850) and
+// rng.hpp:5-40, including the behaviours listed in oracle/hanabi_oracle.c
+// (plausibility bits test bit <player-loop-index>; only the player to move is
+// re-encoded; hint legality scans all five slots; no legality check).  Actions
+// outside an agent's legal-move mask are outside the contract (the reference
+// then overruns its own encoders); here they are memory-safe but unspecified.
+//
+// Mapping.  A world's step is serial (one deck, one player to move), but its
+// output is 1.5 KB of 0/1 bytes.  So the work is split inside one wave:
+//   phase A  lane = world (kWorldsPerWave lanes active): apply the action on the
+//            176-byte game record staged in LDS, then build the observation as a
+//            783-bit vector (658 obs bits + 125 own-hand bits) and the 20 legal
+//            moves as a bit mask, with a handful of shifted ORs per section;
+//   phase B  all 64 lanes: expand bits to bytes, 16 bits -> one 16-byte store, so
+//            every row is written with full-width coalesced stores.
+// Rows are padded to 16-byte multiples in HBM (obs 672, state 784) and exported
+// as strided (2, N, 658) / (2, N, 783) views.
+//
+// Episode indices come from one global counter in the reference
+// (sim.cpp:449-451).  As for Cartpole the order is fixed to ascending world
+// index, which needs a prefix sum over the done flags: step = two launches,
+//   mrl_hanabi_step : action + encode + score/done + per-workgroup done counts
+//   mrl_hanabi_reset: prefix over the counts, re-deal finished worlds, encode both agents
 #include "common.hpp"
-mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *, int, uint32_t)
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kWorldsPerWave = 16;
+constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
+
+constexpr int kHand = 5;
+constexpr int kRecordBytes = 176;
+constexpr int kRecordWords = kRecordBytes / 4;
+constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-record accesses spread over banks
+constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
+constexpr int kObsRow = 672, kStateRow = 784;
+constexpr int kObsChunks = kObsRow / 16, kStateChunks = kStateRow / 16, kMaskChunks = 5;
+constexpr int kChunksPerAgent = kObsChunks + kStateChunks + kMaskChunks;  // 96
+
+// record layout (bytes); identical to oracle/hanabi_oracle.c's dump
+enum : int {
+    R_DECK = 0, R_DECK_SIZE = 50, R_DISCARD = 51, R_FIREWORKS = 76, R_INFO = 81, R_LIFE = 82, R_CUR = 83,
+    R_TURNS = 84, R_SCORE = 85, R_NEWREW = 86,
+    R_LM_MOVE = 87, R_LM_PLAYER = 88, R_LM_TARGET = 89, R_LM_INDEX = 90, R_LM_SCORED = 91, R_LM_INFOTOK = 92,
+    R_LM_COLOR = 93, R_LM_RANK = 94, R_LM_REVEAL = 95, R_LM_NEWLY = 96, R_LM_DEALTO = 97,
+    R_HAND = 100, HAND_BYTES = 36, H_CARDS = 0, H_SIZE = 5, H_KCOLOR = 6, H_KRANK = 11, H_PLAUS = 16,
+    R_RNG = 172
+};
+enum : uint32_t { MV_DISCARD = 0, MV_PLAY = 1, MV_REVEAL_COLOR = 2, MV_REVEAL_RANK = 3, MV_INVALID = 4 };
+
+struct HanabiParams {
+    uint32_t num_worlds;
+    uint32_t colors, ranks, max_info, max_life;
+    // bit offsets of the observation sections
+    uint32_t bpc, max_deck;
+    uint32_t off_flags, off_deck, off_fireworks, off_info, off_life, off_discard, off_last, off_know;
+    uint32_t obs_bits, state_bits;
+    uint32_t *records;   // N x 44 words
+    uint8_t *obs;        // 2 x N x 672
+    uint8_t *state;      // 2 x N x 784
+    int32_t *mask;       // 2 x N x 20
+    int32_t *active;     // 2 x N
+    float *reward;       // 2 x N
+    int32_t *done;       // N
+    const int32_t *actions;  // 2 x N
+    uint32_t *block_counts;
+};
+
+__device__ __forceinline__ void wave_lds_sync()
 {
-    set_error("hanabi: not built yet");
-    throw HipError{MRL_ERR_INVALID};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t seed_of(uint32_t episode)
+{
+    uint32_t v0 = episode, v1 = 0, sum = 0;
+#pragma unroll
+    for (int round = 0; round < 8; round++) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+__device__ __forceinline__ uint32_t &rng_of(uint8_t *rec) { return *reinterpret_cast<uint32_t *>(rec + R_RNG); }
+__device__ __forceinline__ uint32_t *plaus_of(uint8_t *hand) { return reinterpret_cast<uint32_t *>(hand + H_PLAUS); }
+
+// sim.cpp:45-52 (one float multiply, truncation)
+__device__ __forceinline__ uint32_t draw(uint8_t *rec)
+{
+    uint32_t &g = rng_of(rec);
+    g = 1664525u * g + 1013904223u;
+    const float r = (float)(g & 0x00FFFFFFu) / (float)0x01000000;
+    const uint32_t size = rec[R_DECK_SIZE];
+    const int32_t at = (int32_t)((float)size * r);
+    const uint8_t card = rec[R_DECK + at];
+    rec[R_DECK + at] = rec[R_DECK + size - 1];
+    rec[R_DECK_SIZE] = (uint8_t)(size - 1);
+    return card;
+}
+
+__device__ __forceinline__ void put(uint32_t *enc, uint32_t off, uint32_t nbits, uint32_t value)
+{
+    const uint32_t w = off >> 5, s = off & 31;
+    enc[w] |= value << s;
+    if (s + nbits > 32) enc[w + 1] |= value >> (32 - s);
+}
+
+__device__ __forceinline__ uint32_t ones(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u; }
+
+// sim.cpp:367-379 as a bit vector: bits [0, obs_bits) = observation of `agent`,
+// bits [obs_bits, state_bits) = its own hand; enc[25] = legal moves (sim.cpp:381-444)
+__device__ void encode_agent(const HanabiParams &p, uint8_t *rec, uint32_t *enc, uint32_t agent)
+{
+    const uint32_t K = p.colors, R = p.ranks, bpc = p.bpc;
+    for (int w = 0; w < kEncWords; w++) enc[w] = 0;
+    uint8_t *own = rec + R_HAND + HAND_BYTES * agent;
+    uint8_t *other = rec + R_HAND + HAND_BYTES * (agent ^ 1u);
+    const uint32_t own_size = own[H_SIZE], other_size = other[H_SIZE];
+
+    // partner hand + "short hand" flags (:54-90)
+    for (uint32_t c = 0; c < kHand; c++)
+        if (c < other_size) put(enc, c * bpc + other[H_CARDS + c], 1, 1);
+    put(enc, p.off_flags, 2, (own_size < kHand ? 1u : 0u) | (other_size < kHand ? 2u : 0u));
+
+    // board (:92-135)
+    const uint32_t deck = min((uint32_t)rec[R_DECK_SIZE], p.max_deck);
+    put(enc, p.off_deck, min(deck, 32u), ones(min(deck, 32u)));
+    if (deck > 32) put(enc, p.off_deck + 32, deck - 32, ones(deck - 32));
+    uint32_t fw = 0;
+    for (uint32_t c = 0; c < K; c++) {
+        const uint32_t f = rec[R_FIREWORKS + c];
+        if (f >= 1 && f <= R) fw |= 1u << (c * R + f - 1);
+    }
+    put(enc, p.off_fireworks, K * R, fw);
+    // The reference writes with a running offset, so information tokens beyond the
+    // maximum (a rank-5 card played at full tokens adds one unconditionally,
+    // sim.cpp:676-678) lengthen this thermometer and move every later section up.
+    const uint32_t info_now = min((uint32_t)rec[R_INFO], p.max_info + 5u);
+    const uint32_t excess = info_now > p.max_info ? info_now - p.max_info : 0u;
+    put(enc, p.off_info, p.max_info + excess, ones(info_now));
+    put(enc, p.off_life + excess, p.max_life, ones(min((uint32_t)rec[R_LIFE], p.max_life)));
+    enc[26] = excess;
+
+    // discards (:137-156): per colour, thermometers of 3 / 2.. / 1 copies
+    for (uint32_t c = 0; c < K; c++) {
+        uint32_t bits = 0, at = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t copies = r == 0 ? 3u : (r == R - 1 ? 1u : 2u);
+            bits |= ones(min((uint32_t)rec[R_DISCARD + c * R + r], copies)) << at;
+            at += copies;
+        }
+        put(enc, p.off_discard + excess + c * 2 * R, 2 * R, bits);
+    }
+
+    // last action (:158-289)
+    {
+        const uint32_t move = rec[R_LM_MOVE];
+        const int32_t lm_player = (int8_t)rec[R_LM_PLAYER];
+        const bool hint = move == MV_REVEAL_COLOR || move == MV_REVEAL_RANK;
+        const bool card = move == MV_PLAY || move == MV_DISCARD;
+        uint32_t v = 0, at = 0;
+        if (lm_player != -1) v |= 1u << (((int32_t)agent - lm_player + 2) & 1);
+        at += 2;
+        if (move == MV_PLAY) v |= 1u << at;
+        else if (move == MV_DISCARD) v |= 2u << at;
+        else if (move == MV_REVEAL_COLOR) v |= 4u << at;
+        else if (move == MV_REVEAL_RANK) v |= 8u << at;
+        at += 4;
+        if (hint) v |= 1u << (at + (((int32_t)agent - (int32_t)(int8_t)rec[R_LM_TARGET] + 2) & 1));
+        at += 2;
+        if (move == MV_REVEAL_COLOR && (uint32_t)rec[R_LM_COLOR] < K) v |= 1u << (at + rec[R_LM_COLOR]);
+        at += K;
+        if (move == MV_REVEAL_RANK && (uint32_t)rec[R_LM_RANK] < R) v |= 1u << (at + rec[R_LM_RANK]);
+        at += R;
+        const uint32_t off_last = p.off_last + excess;
+        put(enc, off_last, at, v);
+        uint32_t v2 = 0;
+        if (hint) v2 |= rec[R_LM_REVEAL] & 31u;
+        if (card && (uint32_t)rec[R_LM_INDEX] < kHand) v2 |= 1u << (kHand + rec[R_LM_INDEX]);
+        put(enc, off_last + at, 2 * kHand, v2);
+        if (card) {
+            const uint32_t id = (uint32_t)rec[R_LM_COLOR] * R + rec[R_LM_RANK];
+            if (id < bpc) put(enc, off_last + at + 2 * kHand + id, 1, 1);
+        }
+        if (move == MV_PLAY)
+            put(enc, off_last + at + 2 * kHand + bpc, 2, (rec[R_LM_SCORED] ? 1u : 0u) | (rec[R_LM_INFOTOK] ? 2u : 0u));
+    }
+
+    // card knowledge (:291-331): own hand first, then the partner's
+    for (uint32_t i = 0; i < 2; i++) {
+        uint8_t *h = i == 0 ? own : other;
+        const uint32_t size = h[H_SIZE];
+        const uint32_t *plaus = plaus_of(h);
+        for (uint32_t c = 0; c < kHand; c++) {
+            if (c >= size) continue;
+            const uint32_t base = p.off_know + excess + (i * kHand + c) * (bpc + K + R);
+            if ((plaus[c] >> i) & 1u) put(enc, base, bpc, ones(bpc));  // sim.cpp:311: bit <i>, not bit <v>
+            uint32_t kr = 0;
+            const int32_t kc = (int8_t)h[H_KCOLOR + c], kk = (int8_t)h[H_KRANK + c];
+            if (kc >= 0 && (uint32_t)kc < K) kr |= 1u << kc;
+            if (kk >= 0 && (uint32_t)kk < R) kr |= 1u << (K + kk);
+            put(enc, base + bpc, K + R, kr);
+        }
+    }
+
+    // state tail: own hand (:343-365)
+    for (uint32_t c = 0; c < kHand; c++)
+        if (c < own_size) put(enc, p.obs_bits + excess + c * bpc + own[H_CARDS + c], 1, 1);
+
+    // legal moves (:381-444)
+    uint32_t legal = 0;
+    const uint32_t info = rec[R_INFO];
+    for (uint32_t i = 0; i < kHand; i++) {
+        if (i < own_size && info < p.max_info) legal |= 1u << i;
+        if (i < own_size) legal |= 1u << (kHand + i);
+    }
+    if (info > 0) {
+        for (uint32_t n = 0; n < kHand; n++) {  // all five slots, whatever the hand size (:416-417)
+            const uint32_t card = other[H_CARDS + n];
+            const uint32_t col = card / R, rk = card % R;
+            if (col < K) legal |= 1u << (2 * kHand + col);
+            legal |= 1u << (2 * kHand + K + rk);
+        }
+    }
+    enc[25] = legal & 0xFFFFFu;
+}
+
+// sim.cpp:567-594
+__device__ __forceinline__ void take_from_hand(const HanabiParams &p, uint8_t *rec, uint8_t *hand, uint32_t index)
+{
+    uint32_t *plaus = plaus_of(hand);
+    if (rec[R_DECK_SIZE] == 0) {
+        const uint32_t size = hand[H_SIZE];
+        for (uint32_t i = index + 1; i < size && i < kHand; i++) {
+            hand[H_CARDS + i - 1] = hand[H_CARDS + i];
+            plaus[i - 1] = plaus[i];
+            hand[H_KCOLOR + i - 1] = hand[H_KCOLOR + i];
+            hand[H_KRANK + i - 1] = hand[H_KRANK + i];
+        }
+        hand[H_SIZE] = (uint8_t)(size - 1);
+    } else {
+        hand[H_CARDS + index] = (uint8_t)draw(rec);
+        plaus[index] = ones(p.bpc);
+        hand[H_KCOLOR + index] = 0xFF;
+        hand[H_KRANK + index] = 0xFF;
+    }
+}
+
+// sim.cpp:596-792
+__device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
+{
+    const uint32_t K = p.colors, R = p.ranks;
+    if (rec[R_DECK_SIZE] == 0) rec[R_TURNS] = (uint8_t)(rec[R_TURNS] - 1);
+    const uint32_t actor = rec[R_CUR] & 1u;
+    uint8_t *hand = rec + R_HAND + HAND_BYTES * actor;
+
+    rec[R_LM_PLAYER] = (uint8_t)actor;
+    rec[R_LM_TARGET] = 0xFF;
+    rec[R_LM_INDEX] = 0xFF;
+    rec[R_LM_SCORED] = 0;
+    rec[R_LM_INFOTOK] = 0;
+    rec[R_LM_COLOR] = 0xFF;
+    rec[R_LM_RANK] = 0xFF;
+    rec[R_LM_REVEAL] = 0;
+    rec[R_LM_NEWLY] = 0;
+    rec[R_LM_DEALTO] = 0xFF;
+    rec[R_CUR] = (uint8_t)(actor ^ 1u);
+
+    if (uid < 2 * kHand) {
+        const bool play = uid >= kHand;
+        const uint32_t slot = play ? uid - kHand : uid;
+        const uint32_t card = min((uint32_t)hand[H_CARDS + slot], 24u);
+        const uint32_t col = card / R, rk = card % R;
+        rec[R_LM_MOVE] = play ? MV_PLAY : MV_DISCARD;
+        rec[R_LM_INDEX] = (uint8_t)slot;
+        rec[R_LM_COLOR] = (uint8_t)col;
+        rec[R_LM_RANK] = (uint8_t)rk;
+        if (!play) {
+            rec[R_DISCARD + card]++;
+            rec[R_INFO]++;
+        } else if (col < 5 && rec[R_FIREWORKS + col] == rk) {
+            rec[R_FIREWORKS + col]++;
+            if (rec[R_FIREWORKS + col] == R) {
+                rec[R_INFO]++;
+                rec[R_LM_INFOTOK] = 1;
+            }
+            rec[R_LM_SCORED] = 1;
+        } else {
+            rec[R_DISCARD + card]++;
+            rec[R_LIFE]--;
+        }
+        take_from_hand(p, rec, hand, slot);
+        return;
+    }
+    uid -= 2 * kHand;
+    uint8_t *ph = rec + R_HAND + HAND_BYTES * (actor ^ 1u);  // one partner: target_offset is always 1
+    uint32_t *plaus = plaus_of(ph);
+    const uint32_t psize = min((uint32_t)ph[H_SIZE], (uint32_t)kHand);
+    rec[R_INFO]--;
+    rec[R_LM_TARGET] = (uint8_t)(actor ^ 1u);
+    uint32_t reveal = 0, newly = 0, hint = 0;
+    if (uid < K) {
+        const uint32_t col = uid;
+        rec[R_LM_MOVE] = MV_REVEAL_COLOR;
+        rec[R_LM_COLOR] = (uint8_t)col;
+        for (uint32_t i = 0; i < R; i++) hint |= 1u << (col * R + i);
+        for (uint32_t i = 0; i < psize; i++) {
+            if (ph[H_CARDS + i] / R == col) {
+                reveal |= 1u << i;
+                if ((int8_t)ph[H_KCOLOR + i] == -1) newly |= 1u << i;
+                ph[H_KCOLOR + i] = (uint8_t)col;
+                plaus[i] &= hint;
+            } else {
+                plaus[i] &= ~hint;
+            }
+        }
+    } else {
+        const uint32_t rk = (uid - K) % R;
+        rec[R_LM_MOVE] = MV_REVEAL_RANK;
+        rec[R_LM_RANK] = (uint8_t)rk;
+        for (uint32_t i = 0; i < R; i++) hint |= 1u << (i * R + rk);
+        for (uint32_t i = 0; i < psize; i++) {
+            if (ph[H_CARDS + i] % R == rk) {
+                reveal |= 1u << i;
+                if ((int8_t)ph[H_KCOLOR + i] == -1) newly |= 1u << i;  // sim.cpp:776 tests known_color here too
+                ph[H_KRANK + i] = (uint8_t)rk;
+                plaus[i] &= hint;
+            } else {
+                plaus[i] &= ~hint;
+            }
+        }
+    }
+    rec[R_LM_REVEAL] = (uint8_t)reveal;
+    rec[R_LM_NEWLY] = (uint8_t)newly;
+}
+
+// sim.cpp:446-532, without the encode
+__device__ void deal_new_game(const HanabiParams &p, uint8_t *rec, uint32_t episode)
+{
+    const uint32_t K = p.colors, R = p.ranks;
+    for (int w = 0; w < kRecordWords; w++) reinterpret_cast<uint32_t *>(rec)[w] = 0;
+    rng_of(rec) = seed_of(episode);
+    uint32_t k = 0;
+    for (uint32_t c = 0; c < K; c++)
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t copies = r == 0 ? 3u : (r == R - 1 ? 1u : 2u);
+            for (uint32_t i = 0; i < copies; i++) rec[R_DECK + k++] = (uint8_t)(R * c + r);
+        }
+    rec[R_DECK_SIZE] = (uint8_t)k;
+    rec[R_INFO] = (uint8_t)p.max_info;
+    rec[R_LIFE] = (uint8_t)p.max_life;
+    rec[R_CUR] = 0;
+    rec[R_TURNS] = 2;
+    rec[R_LM_MOVE] = MV_INVALID;
+    rec[R_LM_PLAYER] = 0xFF;
+    rec[R_LM_TARGET] = 0xFF;
+    rec[R_LM_INDEX] = 0xFF;
+    rec[R_LM_COLOR] = 0xFF;
+    rec[R_LM_RANK] = 0xFF;
+    rec[R_LM_DEALTO] = 0xFF;
+    for (uint32_t a = 0; a < 2; a++) {
+        uint8_t *h = rec + R_HAND + HAND_BYTES * a;
+        for (uint32_t j = 0; j < kHand; j++) {
+            h[H_CARDS + j] = (uint8_t)draw(rec);
+            plaus_of(h)[j] = ones(p.bpc);
+            h[H_KCOLOR + j] = 0xFF;
+            h[H_KRANK + j] = 0xFF;
+        }
+        h[H_SIZE] = kHand;
+    }
+}
+
+__device__ __forceinline__ uint32_t spread4(uint32_t bits)
+{
+    // 4 bits -> 4 bytes of 0/1 (the shifted copies do not overlap, so no carries)
+    return ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+}
+
+// phase B for one (world, agent): lanes cover the 96 16-byte chunks
+__device__ __forceinline__ void expand_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t agent, uint32_t world,
+                                             uint32_t chunk)
+{
+    const size_t row = (size_t)agent * p.num_worlds + world;
+    if (chunk < kObsChunks + kStateChunks) {
+        const bool is_state = chunk >= kObsChunks;
+        const uint32_t k = is_state ? chunk - kObsChunks : chunk;
+        // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the
+        // shifted encoding pushes past the row end is dropped (the reference writes it out of bounds)
+        const uint32_t limit = is_state ? min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE)
+                                        : min(p.obs_bits + enc[26], (uint32_t)MRL_HANABI_OBS_SIZE);
+        uint32_t bits = (enc[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
+        const uint32_t first = k * 16u;
+        if (first >= limit) bits = 0;
+        else if (first + 16u > limit) bits &= ones(limit - first);
+        const uint4 v = make_uint4(spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12));
+        uint8_t *dst = is_state ? p.state + row * kStateRow : p.obs + row * kObsRow;
+        reinterpret_cast<uint4 *>(dst)[k] = v;
+    } else {
+        const uint32_t m = chunk - (kObsChunks + kStateChunks);
+        const uint32_t bits = enc[25] >> (4u * m);
+        reinterpret_cast<uint4 *>(p.mask + row * 20)[m] = make_uint4(bits & 1u, (bits >> 1) & 1u, (bits >> 2) & 1u, (bits >> 3) & 1u);
+    }
+}
+
+struct WaveLds {
+    uint8_t *rec;    // kWorldsPerWave x kRecStride
+    uint32_t *enc;   // kWorldsPerWave x 2 x kEncWords
+};
+
+constexpr int kWaveLdsBytes = kWorldsPerWave * kRecStride + kWorldsPerWave * 2 * kEncWords * 4;
+
+__device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
+{
+    uint8_t *base = smem + wib * kWaveLdsBytes;
+    return WaveLds{base, reinterpret_cast<uint32_t *>(base + kWorldsPerWave * kRecStride)};
+}
+
+__device__ __forceinline__ void load_records(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t nw, uint32_t lane)
+{
+    for (uint32_t i = lane; i < nw * kRecordWords; i += kWave) {
+        const uint32_t r = i / kRecordWords, k = i - r * kRecordWords;
+        reinterpret_cast<uint32_t *>(l.rec + r * kRecStride)[k] = p.records[(size_t)w0 * kRecordWords + i];
+    }
+}
+
+__device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t r, uint32_t lane)
+{
+    if (lane < kRecordWords)
+        p.records[(size_t)(w0 + r) * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
+}
+
+__global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t w0 = blockIdx.x * kWorldsPerBlock + wib * kWorldsPerWave;
+    const uint32_t nw = w0 < p.num_worlds ? min((uint32_t)kWorldsPerWave, p.num_worlds - w0) : 0u;
+    const WaveLds l = wave_lds(smem, wib);
+    const uint32_t N = p.num_worlds;
+
+    load_records(p, l, w0, nw, lane);
+    wave_lds_sync();
+
+    bool over = false;
+    if (lane < nw) {
+        uint8_t *rec = l.rec + lane * kRecStride;
+        uint32_t *enc = l.enc + lane * 2 * kEncWords;
+        const uint32_t world = w0 + lane;
+        const uint32_t actor = rec[R_CUR] & 1u;
+        apply_action(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
+        const uint32_t next = rec[R_CUR] & 1u;
+        // observationSystem (:794-810): only the player to move is refreshed
+        encode_agent(p, rec, enc, next);
+        p.active[(size_t)next * N + world] = 1;
+        p.active[(size_t)(next ^ 1u) * N + world] = 0;
+        // checkDone (:812-850)
+        const int32_t old_score = (int8_t)rec[R_SCORE];
+        int32_t score = 0;
+        if (rec[R_LIFE] > 0)
+            for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
+        rec[R_SCORE] = (uint8_t)score;
+        rec[R_NEWREW] = (uint8_t)(score - old_score);
+        const float rew = (float)(int8_t)(score - old_score);
+        p.reward[world] = rew;
+        p.reward[(size_t)N + world] = rew;
+        over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * p.ranks || (int8_t)rec[R_TURNS] <= 0;
+        p.done[world] = over ? 1 : 0;
+    }
+    const unsigned long long votes = __ballot(over);
+    wave_lds_sync();
+
+    // phase B: bits -> bytes for every world's player to move
+    for (uint32_t task = lane; task < nw * kChunksPerAgent; task += kWave) {
+        const uint32_t r = task / kChunksPerAgent, chunk = task - r * kChunksPerAgent;
+        const uint32_t agent = l.rec[r * kRecStride + R_CUR] & 1u;
+        expand_chunk(p, l.enc + r * 2 * kEncWords, agent, w0 + r, chunk);
+    }
+    for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
+
+    if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
+    __syncthreads();
+    if (threadIdx.x == 0) p.block_counts[blockIdx.x] = s_counts[0] + s_counts[1] + s_counts[2] + s_counts[3];
+}
+
+// kAll: (re)initialise every world as episode episode_base + world (construction /
+// mrl_reseed_shard); otherwise only the worlds whose done flag is set, numbered in
+// ascending world order from *episode_base.
+template <bool kAll>
+__global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
+                                                           uint32_t episode_base_value, uint32_t *next_counter,
+                                                           uint32_t *reset_count)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_part[kWavesPerBlock];
+    const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t w0 = blockIdx.x * kWorldsPerBlock + wib * kWorldsPerWave;
+    const uint32_t nw = w0 < p.num_worlds ? min((uint32_t)kWorldsPerWave, p.num_worlds - w0) : 0u;
+    const WaveLds l = wave_lds(smem, wib);
+    const uint32_t N = p.num_worlds;
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+
+    uint32_t prefix = 0;
+    if (!kAll) {
+        if (p.block_counts[blockIdx.x] == 0 && !last_block) return;  // uniform for the workgroup
+        uint32_t mine = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) mine += p.block_counts[b];
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+        if (lane == 0) s_part[wib] = mine;
+        __syncthreads();
+        prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+
+    const bool over = lane < nw && (kAll || p.done[w0 + lane] != 0);
+    const unsigned long long votes = __ballot(over);
+    if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kWavesPerBlock; w++) {
+        before += w < wib ? s_counts[w] : 0u;
+        total += s_counts[w];
+    }
+    const uint32_t base = kAll ? episode_base_value : *episode_base;
+    if (!kAll && last_block && threadIdx.x == 0) {
+        *reset_count = prefix + total;
+        *next_counter = base + prefix + total;
+    }
+    if (votes == 0ull) return;
+
+    if (over) {
+        uint8_t *rec = l.rec + lane * kRecStride;
+        const uint32_t rank = kAll ? (w0 + lane) : prefix + before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+        deal_new_game(p, rec, base + rank);
+        encode_agent(p, rec, l.enc + lane * 2 * kEncWords, 0);
+        encode_agent(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
+        p.active[w0 + lane] = 1;
+        p.active[(size_t)N + w0 + lane] = 0;
+        if (kAll) {
+            p.reward[w0 + lane] = 0.f;
+            p.reward[(size_t)N + w0 + lane] = 0.f;
+            p.done[w0 + lane] = 0;
+        }
+    }
+    wave_lds_sync();
+    unsigned long long todo = votes;
+    while (todo) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        for (uint32_t task = lane; task < 2 * kChunksPerAgent; task += kWave) {
+            const uint32_t agent = task / kChunksPerAgent, chunk = task - agent * kChunksPerAgent;
+            expand_chunk(p, l.enc + (r * 2 + agent) * kEncWords, agent, w0 + r, chunk);
+        }
+        store_record(p, l, w0, r, lane);
+    }
+}
+
+__global__ void fill_agent_ids(int32_t *world_id, int32_t *agent_id, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n) {
+        world_id[i] = (int32_t)(i % n);
+        agent_id[i] = (int32_t)(i / n);
+    }
+}
+
+struct HanabiSim final : mrl_sim {
+    HanabiParams params{};
+    uint32_t grid = 0;
+    int32_t *action = nullptr, *world_id = nullptr, *agent_id = nullptr;
+    uint32_t *counter = nullptr, *reset_count = nullptr;
+    uint32_t parity = 0;
+
+    void phase1(const int32_t *actions, hipStream_t stream) override
+    {
+        HanabiParams a = params;
+        a.actions = actions ? actions : action;
+        hipLaunchKernelGGL(mrl_hanabi_step, dim3(grid), dim3(kBlock), 0, stream, a);
+        MRL_HIP(hipGetLastError());
+    }
+
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
+        hipLaunchKernelGGL(mrl_hanabi_reset<false>, dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
+                           counter + (parity ^ 1u), reset_count);
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
+
+    void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
+    {
+        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        MRL_HIP(hipStreamSynchronize(stream));
+    }
+
+    void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl_hanabi_reset<true>, dim3(grid), dim3(kBlock), 0, stream, params,
+                           (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        MRL_HIP(hipGetLastError());
+        set_episode_counter(num_worlds_total, stream);
+    }
+
+    bool tensor(int slot, mrl_tensor_desc *out) override
+    {
+        const int64_t N = num_worlds;
+        switch (slot) {
+        case MRL_HANABI_DONE: *out = mrl::make_desc(params.done, MRL_INT32, device, {N}); return true;
+        case MRL_HANABI_ACTIVE_AGENT: *out = mrl::make_desc(params.active, MRL_INT32, device, {2, N}); return true;
+        case MRL_HANABI_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {2, N, 1}); return true;
+        case MRL_HANABI_OBSERVATION:
+            *out = mrl::make_desc(params.obs, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {N * kObsRow, kObsRow, 1});
+            return true;
+        case MRL_HANABI_ACTION_MASK: *out = mrl::make_desc(params.mask, MRL_INT32, device, {2, N, 20}); return true;
+        case MRL_HANABI_REWARD: *out = mrl::make_desc(params.reward, MRL_FLOAT32, device, {2, N}); return true;
+        case MRL_HANABI_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {2, N}); return true;
+        case MRL_HANABI_AGENT_ID: *out = mrl::make_desc(agent_id, MRL_INT32, device, {2, N}); return true;
+        case MRL_HANABI_STATE:
+            *out = mrl::make_desc(params.state, MRL_INT8, device, {2, N, MRL_HANABI_STATE_SIZE},
+                                  {N * kStateRow, kStateRow, 1});
+            return true;
+        case MRL_HANABI_GAME: *out = mrl::make_desc(params.records, MRL_UINT8, device, {N, kRecordBytes}); return true;
+        case MRL_HANABI_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        default: return false;
+        }
+    }
+
+    const char *kernel_name() const override { return "mrl_hanabi_step"; }
+
+    uint64_t bytes_per_world_step() const override
+    {
+        // action 8 + record r/w 2*176 + obs 658 + state 783 + mask 80 +
+        // active 8 + reward 8 + done 4 (non-reset step: one agent re-encoded)
+        return 8 + 2 * kRecordBytes + 658 + 783 + 80 + 8 + 8 + 4;
+    }
+};
+
+}  // namespace
+
+mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds)
+{
+    if (!cfg) {
+        set_error("hanabi: null config");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    if (cfg->players != 2) {
+        set_error("hanabi: players must be 2 (the reference's tensors are compiled for N_PLAYERS=2, "
+                  "src/hanabi_env/sim.hpp:23), got %u",
+                  cfg->players);
+        throw HipError{MRL_ERR_INVALID};
+    }
+    if (cfg->colors < 1 || cfg->colors > 5 || cfg->ranks < 2 || cfg->ranks > 5 || cfg->max_information_tokens < 1 ||
+        cfg->max_information_tokens > 8 || cfg->max_life_tokens < 1 || cfg->max_life_tokens > 3) {
+        set_error("hanabi: need 1..5 colors, 2..5 ranks, 1..8 information tokens, 1..3 life tokens");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    if (num_worlds == 0) {
+        set_error("hanabi: num_worlds must be > 0");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    bind_device(gpu_id);
+    auto *sim = new HanabiSim();
+    try {
+        sim->game = MRL_GAME_HANABI;
+        sim->device = gpu_id;
+        sim->num_worlds = num_worlds;
+        sim->grid = (num_worlds + kWorldsPerBlock - 1) / kWorldsPerBlock;
+        HanabiParams &a = sim->params;
+        const uint32_t K = cfg->colors, R = cfg->ranks, N = num_worlds;
+        a.num_worlds = N;
+        a.colors = K;
+        a.ranks = R;
+        a.max_info = cfg->max_information_tokens;
+        a.max_life = cfg->max_life_tokens;
+        a.bpc = K * R;
+        a.max_deck = (4 + (R - 2) * 2) * K - 2 * kHand;
+        a.off_flags = kHand * a.bpc;
+        a.off_deck = a.off_flags + 2;
+        a.off_fireworks = a.off_deck + a.max_deck;
+        a.off_info = a.off_fireworks + K * R;
+        a.off_life = a.off_info + a.max_info;
+        a.off_discard = a.off_life + a.max_life;
+        a.off_last = a.off_discard + 2 * R * K;
+        a.off_know = a.off_last + (2 + 4 + 2 + K + R + 2 * kHand + a.bpc + 2);
+        a.obs_bits = a.off_know + 2 * kHand * (a.bpc + K + R);
+        a.state_bits = a.obs_bits + kHand * a.bpc;
+        if ((int32_t)a.max_deck < 0 || a.state_bits > 780 + 3) {
+            set_error("hanabi: configuration does not leave a deck after dealing two hands");
+            throw HipError{MRL_ERR_INVALID};
+        }
+        a.records = sim->arena.alloc<uint32_t>((size_t)N * kRecordWords);
+        a.obs = sim->arena.alloc<uint8_t>((size_t)2 * N * kObsRow);
+        a.state = sim->arena.alloc<uint8_t>((size_t)2 * N * kStateRow);
+        a.mask = sim->arena.alloc<int32_t>((size_t)2 * N * 20);
+        a.active = sim->arena.alloc<int32_t>((size_t)2 * N);
+        a.reward = sim->arena.alloc<float>((size_t)2 * N);
+        a.done = sim->arena.alloc<int32_t>(N);
+        a.block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        sim->action = sim->arena.alloc<int32_t>((size_t)2 * N);
+        sim->world_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
+        sim->agent_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
+        sim->counter = sim->arena.alloc<uint32_t>(2);
+        sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        hipLaunchKernelGGL(fill_agent_ids, dim3((2 * N + 255) / 256), dim3(256), 0, 0, sim->world_id, sim->agent_id, N);
+        MRL_HIP(hipGetLastError());
+        sim->reseed_shard(0, N, 0);
+        MRL_HIP(hipDeviceSynchronize());
+    } catch (...) {
+        delete sim;
+        throw;
+    }
+    return sim;
 }

@@ -70,9 +70,10 @@ typedef struct {
  *   [81] info [82] life [83] cur_player [84] turns_to_play [85] score [86] new_rew
  *   [87..97] last move (move, player, target, card_index, scored, info_token,
  *            color, rank, reveal, newly_revealed, deal_to)
- *   per hand h (base 98 + 36*h): cards[5], size, known_color[5], known_rank[5],
- *            plausible[5] as uint32 LE (20 bytes)
- *   [170..173] rng state (uint32 LE)
+ *   [98..99] padding
+ *   per hand h (base 100 + 36*h): cards[5], size, known_color[5], known_rank[5],
+ *            plausible[5] as uint32 LE (20 bytes, 4-byte aligned)
+ *   [172..175] rng state (uint32 LE)
  */
 #define RECORD_BYTES 176
 
@@ -120,7 +121,15 @@ static uint8_t draw(game_t *g)
 static void encode_agent(orc_hanabi *s, uint32_t wi, int agent)
 {
     game_t *g = &s->games[wi];
-    uint8_t *o = obs_of(s, agent, wi);
+    /* The reference advances a running offset while it writes (sim.cpp:54-365), so
+     * when information_tokens exceeds its maximum (a rank-5 card played at full
+     * tokens: sim.cpp:676-678 adds the token unconditionally) the token
+     * thermometer is longer and every later section moves up.  For the full
+     * configuration the last byte then lands one past the 658-byte row -- an
+     * out-of-bounds write in the reference; here the row is encoded in a scratch
+     * buffer and only what fits the row is kept. */
+    uint8_t scratch[ORC_HANABI_STATE + 64];
+    uint8_t *o = scratch;
     const uint32_t colors = s->colors, ranks = s->ranks, np = s->players, hs = s->hand_size;
     const int bpc = (int)(colors * ranks);
     int at = 0;
@@ -202,13 +211,14 @@ static void encode_agent(orc_hanabi *s, uint32_t wi, int agent)
     }
 
     /* state = obs prefix + own hand (:333-365) */
-    uint8_t *st = state_of(s, agent, wi);
-    memcpy(st, o, (size_t)at);
+    const int obs_len = at;
     const hand_t *own = &g->hands[agent];
     for (int c = 0; c < own->size; c++)
-        for (int b = 0; b < bpc; b++) st[at++] = (b == own->cards[c]);
+        for (int b = 0; b < bpc; b++) o[at++] = (b == own->cards[c]);
     for (uint32_t c = own->size; c < hs; c++)
-        for (int b = 0; b < bpc; b++) st[at++] = 0;
+        for (int b = 0; b < bpc; b++) o[at++] = 0;
+    memcpy(obs_of(s, agent, wi), scratch, (size_t)(obs_len < ORC_HANABI_OBS ? obs_len : ORC_HANABI_OBS));
+    memcpy(state_of(s, agent, wi), scratch, (size_t)(at < ORC_HANABI_STATE ? at : ORC_HANABI_STATE));
 }
 
 /* sim.cpp:381-444 */
@@ -537,7 +547,7 @@ void orc_hanabi_dump(const orc_hanabi *s, uint8_t *records)
         r[97] = (uint8_t)lm->deal_to_player;
         for (int hnd = 0; hnd < NPLAYERS; hnd++) {
             const hand_t *h = &g->hands[hnd];
-            uint8_t *b = r + 98 + 36 * hnd;
+            uint8_t *b = r + 100 + 36 * hnd;
             memcpy(b, h->cards, HAND);
             b[5] = h->size;
             memcpy(b + 6, h->known_color, HAND);
@@ -547,6 +557,6 @@ void orc_hanabi_dump(const orc_hanabi *s, uint8_t *records)
                 memcpy(b + 16 + 4 * c, &m, 4);
             }
         }
-        memcpy(r + 170, &g->rng, 4);
+        memcpy(r + 172, &g->rng, 4);
     }
 }
