@@ -1,0 +1,119 @@
+"""Sharding a world batch over the GPUs of one node (one process per GPU,
+``torch.distributed`` with the ``nccl`` backend = RCCL over xGMI; ``gloo`` for
+CPU rehearsal).  The reference is single-device; this
+module is new functionality.
+
+Worlds are independent, so each rank owns a contiguous block
+``[lo, lo + n)`` of the global batch and steps it with its own simulator; no
+collective is needed to *step*.  Two optional exchanges exist:
+
+* ``gather_worlds``: all-gather of a per-rank tensor along its world dimension,
+  for a consumer that wants the global observation batch on every rank
+  (the Overcooked block is world-major, so the gathered buffer *is* the global
+  ``(N, P, H, W, F)`` tensor);
+* the episode-number exchange of Hanabi/Cartpole: the reference seeds every new
+  episode from one global counter (src/hanabi_env/sim.cpp:449-451,
+  src/cartpole_env/sim.cpp:51-53).  To give world ``w`` of a sharded run the same
+  episode sequence as in a single-simulator run, ranks all-gather the number of
+  worlds that finished in this step (one int32 each) between the two phases of
+  the step; everything stays on the device, nothing synchronises the host.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_worlds, rank, world_size):
+    """Contiguous block of worlds owned by ``rank``: (first world, count).
+    The first ``total % world_size`` ranks take one extra world."""
+    base, extra = divmod(int(total_worlds), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, base + (1 if rank < extra else 0)
+
+
+def gather_worlds(local, world_dim=0, group=None, out=None, sizes=None):
+    """All-gather ``local`` along ``world_dim``; every rank gets the global tensor.
+
+    With equal shards (``sizes`` None) this is one ``all_gather_into_tensor``
+    straight into the output when ``world_dim`` is 0 (RCCL: each rank's slab
+    crosses its xGMI links once).  ``sizes`` = per-rank world counts for ragged
+    shards (``shard_range`` gives them without communication)."""
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    if ws == 1:
+        if out is not None:
+            out.copy_(local)
+            return out
+        return local
+    moved = local.movedim(world_dim, 0).contiguous()
+    tail = tuple(moved.shape[1:])
+    if sizes is None:
+        direct = out is not None and world_dim == 0 and out.is_contiguous()
+        buf = out if direct else torch.empty((ws * moved.shape[0],) + tail, dtype=moved.dtype, device=moved.device)
+        dist.all_gather_into_tensor(buf, moved, group=group)
+        if direct:
+            return out
+    else:
+        # ragged shards: pad every slab to the largest, one collective, cut the padding out
+        biggest = max(int(s) for s in sizes)
+        padded = torch.zeros((biggest,) + tail, dtype=moved.dtype, device=moved.device)
+        padded[:moved.shape[0]] = moved
+        slabs = torch.empty((ws * biggest,) + tail, dtype=moved.dtype, device=moved.device)
+        dist.all_gather_into_tensor(slabs, padded, group=group)
+        buf = torch.cat([slabs[r * biggest:r * biggest + int(s)] for r, s in enumerate(sizes)], dim=0)
+    result = buf.movedim(0, world_dim)
+    if out is not None:
+        out.copy_(result)
+        return out
+    return result
+
+
+class ShardedSimulator:
+    """This rank's slice of a ``total_worlds`` batch.
+
+    ``factory(num_worlds)`` builds the rank-local simulator (any of the three
+    games).  For Hanabi/Cartpole the shard is re-seeded so that local world ``i``
+    is global world ``lo + i`` and episode numbering continues from
+    ``total_worlds`` exactly as in a single simulator of the whole batch.
+    """
+
+    def __init__(self, factory, total_worlds, group=None, needs_episode_exchange=True):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.total_worlds = int(total_worlds)
+        self.lo, self.n = shard_range(total_worlds, self.rank, self.world_size)
+        self.sim = factory(self.n)
+        self.needs_episode_exchange = needs_episode_exchange
+        if needs_episode_exchange:
+            self.sim.reseed_shard(self.lo, self.total_worlds)
+            done = self._done_flags()
+            self._counter = torch.full((1,), self.total_worlds, dtype=torch.int32, device=done.device)
+            self._counts = torch.zeros((self.world_size,), dtype=torch.int32, device=done.device)
+
+    def _done_flags(self):
+        sim = self.sim
+        return (sim.done_tensor() if hasattr(sim, "done_tensor") else sim.reset_tensor()).to_torch()
+
+    def step(self, actions=None):
+        """One step of this rank's worlds.  ``actions``: rank-local action tensor
+        (or None to use the simulator's ACTION tensor)."""
+        if not self.needs_episode_exchange:
+            if actions is None:
+                self.sim.step()
+            else:
+                self.sim.step_with_actions(actions)
+            return
+        self.sim.step_phase1(actions)
+        mine = self._done_flags().sum().to(torch.int32).reshape(1)
+        if self.world_size > 1:
+            dist.all_gather_into_tensor(self._counts, mine, group=self.group)
+        else:
+            self._counts.copy_(mine)
+        base = self._counter + self._counts[:self.rank].sum().to(torch.int32)
+        self.sim.step_phase2(base)
+        self._counter = self._counter + self._counts.sum().to(torch.int32)
+
+    def gather(self, local, world_dim=0, out=None):
+        sizes = None
+        if self.total_worlds % self.world_size:
+            sizes = [shard_range(self.total_worlds, r, self.world_size)[1] for r in range(self.world_size)]
+        return gather_worlds(local, world_dim, self.group, out, sizes)

@@ -1,0 +1,87 @@
+"""``OvercookedMadrona`` -- drop-in for /root/reference/envs/overcooked_env.py:18-119.
+
+Same constructor, attributes (``static_actions``, ``static_observations``, ...,
+``sim``) and return shapes.  The reference scatters a (P*C, N, 336)-strided
+export into a (P*C, N, F) copy with an ``index_put`` on every step and then views
+it as (P, N, W, H, F) (overcooked_env.py:92-102); the HIP kernel writes a
+world-major (N, P, H, W, F) block directly, so ``get_obs`` only builds views:
+``obs[:, p].transpose(1, 2)`` has the same shape, dtype and values.
+"""
+import numpy as np
+import torch
+
+from ..layouts import get_base_layout_params  # noqa: F401  (re-export, reference location)
+from ..pantheonrl_extension.vectorenv import VectorMultiAgentEnv
+from ..pantheonrl_extension.vectorobservation import VectorObservation
+from ..simulators import ExecMode, OvercookedSimulator
+from ..spaces import Discrete, MultiBinary
+
+NUM_ACTIONS = 6  # overcooked_ai_py Action.NUM_ACTIONS
+
+
+class OvercookedMadrona(VectorMultiAgentEnv):
+
+    def __init__(self, layout_name, num_envs, gpu_id, debug_compile=True, use_cpu=False, use_env_cpu=False,
+                 ego_agent_idx=0, horizon=400, num_players=None):
+        self.layout_name = layout_name
+        self.base_layout_params = get_base_layout_params(layout_name, horizon, max_num_players=num_players)
+        self.width = self.base_layout_params["width"]
+        self.height = self.base_layout_params["height"]
+        self.num_players = self.base_layout_params["num_players"]
+        self.size = self.width * self.height
+        self.horizon = horizon
+
+        self.sim = OvercookedSimulator(exec_mode=ExecMode.CPU if use_cpu else ExecMode.CUDA, gpu_id=gpu_id,
+                                       num_worlds=num_envs, debug_compile=debug_compile, **self.base_layout_params)
+
+        full_obs_size = self.width * self.height * (5 * self.num_players + 16)
+        self.obs_size = full_obs_size
+        self.state_size = full_obs_size
+
+        self.static_dones = self.sim.done_tensor().to_torch()
+        self.static_active_agents = self.sim.active_agent_tensor().to_torch().to(torch.bool)
+        self.static_actions = self.sim.action_tensor().to_torch()
+        self.static_observations = self.sim.observation_tensor().to_torch()
+        self.static_rewards = self.sim.reward_tensor().to_torch()
+        # (N, P, H, W, F) int8, contiguous: what the kernel writes
+        self.static_world_major_observations = self.sim.observation_world_major_tensor().to_torch()
+        self.static_scattered_active_agents = self.static_active_agents
+        self.static_scattered_rewards = self.static_rewards
+        self.static_scattered_observations = self.static_observations
+
+        env_device = torch.device("cpu") if use_env_cpu else self.static_dones.device
+        super().__init__(num_envs, device=env_device, n_players=self.num_players)
+
+        self.infos = [{}] * self.num_envs
+        self.ego_ind = ego_agent_idx
+        self.observation_space = self._setup_observation_space()
+        self.share_observation_space = self.observation_space
+        self.action_space = Discrete(NUM_ACTIONS)
+        # per-player (N, W, H, F) views are persistent: build them once
+        self._player_views = [self.static_world_major_observations[:, i].transpose(1, 2)
+                              for i in range(self.num_players)]
+        self.n_reset()
+
+    def _setup_observation_space(self):
+        return MultiBinary(np.array([self.width, self.height, 5 * self.num_players + 16]))
+
+    def to_torch(self, a):
+        return a.to(self.device)
+
+    def get_obs(self):
+        return [VectorObservation(self.to_torch(self.static_active_agents[i]), self.to_torch(self._player_views[i]))
+                for i in range(self.n_players)]
+
+    def n_step(self, actions):
+        # (P, N, 1) int64/int32 on any device -> the simulator's int32 action tensor
+        self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
+        self.sim.step()
+        return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
+
+    def n_reset(self):
+        """Like the reference (overcooked_env.py:115-116) this does not restart
+        anything: worlds restart themselves at the horizon inside ``step``."""
+        return self.get_obs()
+
+    def close(self, **kwargs):
+        self.sim.close()

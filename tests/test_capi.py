@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol that
+include/mrl_envs.h declares, and fails loudly (no CPU fallback) when there is
+no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "mrl_envs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree():
+    from madrona_rl_envs_playground_amd import _lib
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for sym in declared_symbols():
+        assert hasattr(hip_lib, sym), f"libmrl_envs.so does not export {sym}"
+    assert hip_lib.mrl_abi_version() == 1
+
+
+def test_library_is_gfx950_only():
+    from madrona_rl_envs_playground_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in blob
+
+
+def test_null_handle_and_bad_slot_are_errors_not_crashes(hip_lib):
+    assert hip_lib.mrl_step(None, None) != 0
+    assert b"null simulator" in hip_lib.mrl_last_error()
+    assert hip_lib.mrl_num_worlds(None) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    from madrona_rl_envs_playground_amd import layouts
+    from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, ExecMode, OvercookedSimulator
+    params = layouts.get_base_layout_params("cramped_room", 400)
+    with pytest.raises(RuntimeError, match="HIP|device|GPU"):
+        OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=4, **params)
+    with pytest.raises(RuntimeError):
+        CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=4)
+    with pytest.raises(NotImplementedError):
+        CartpoleSimulator(exec_mode=ExecMode.CPU, gpu_id=0, num_worlds=4)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(REPO, "madrona_rl_envs_playground_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "mrl_oracle" not in text, f

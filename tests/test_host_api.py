@@ -1,0 +1,122 @@
+"""CPU: host-side logic of the vector-env API (ego/partner plumbing, resampling,
+spaces) with a fake env -- mirrors the behaviour of the reference's
+VectorMultiAgentEnv (pantheonrl_extension/vectorenv.py:26-255)."""
+import numpy as np
+import pytest
+import torch
+
+from madrona_rl_envs_playground_amd import spaces
+from madrona_rl_envs_playground_amd.pantheonrl_extension import (PlayerException, RandomVectorAgent, VectorAgent,
+                                                                 VectorMultiAgentEnv, VectorObservation)
+from madrona_rl_envs_playground_amd.simulators import ExecMode, madrona
+
+
+class CountingEnv(VectorMultiAgentEnv):
+    """obs of player p = step counter + p; reward of player p = sum of actions + p."""
+
+    def __init__(self, n_envs, n_players=2, ego_ind=0):
+        super().__init__(n_envs, torch.device("cpu"), ego_ind=ego_ind, n_players=n_players)
+        self.t = 0
+        self.seen_actions = None
+
+    def _obs_list(self):
+        return [VectorObservation(torch.ones(self.num_envs, dtype=torch.bool),
+                                  torch.full((self.num_envs, 3), self.t + p)) for p in range(self.n_players)]
+
+    def n_step(self, actions):
+        self.seen_actions = actions.clone()
+        self.t += 1
+        rew = torch.stack([actions.sum(0).float().squeeze(-1) + p for p in range(self.n_players)])
+        return self._obs_list(), rew, torch.zeros(self.num_envs, dtype=torch.int32), [{}] * self.num_envs
+
+    def n_reset(self):
+        return self._obs_list()
+
+
+class Recorder(VectorAgent):
+    def __init__(self, value, n):
+        self.value, self.n, self.updates, self.seen = value, n, [], []
+
+    def get_action(self, obs, record=True):
+        self.seen.append(obs.obs.clone())
+        return torch.full((self.n, 1), self.value)
+
+    def update(self, rewards, dones):
+        self.updates.append((rewards.clone(), dones.clone()))
+
+
+def test_vector_observation_defaults():
+    o = VectorObservation(torch.ones(4, dtype=torch.bool), torch.zeros(4, 7))
+    assert o.state is o.obs and o.action_mask is None
+    s = torch.ones(4, 9)
+    assert VectorObservation(o.active, o.obs, s).state is s
+
+
+def test_ego_step_drives_partners():
+    env = CountingEnv(5)
+    partner = Recorder(3, 5)
+    env.add_partner_agent(partner, player_num=1)
+    first = env.reset()
+    assert torch.equal(first.obs, torch.zeros(5, 3))
+    ob, rew, done, info = env.step(torch.full((5, 1), 2))
+    assert env.seen_actions.shape == (2, 5, 1)
+    assert (env.seen_actions[0] == 2).all() and (env.seen_actions[1] == 3).all()
+    assert torch.equal(partner.seen[0], torch.ones(5, 3))          # partner saw its own (player-1) observation
+    assert torch.equal(rew, torch.full((5,), 5.0))                  # ego reward = sum of actions + 0
+    assert torch.equal(partner.updates[0][0], torch.full((5,), 6.0))
+    assert torch.equal(ob.obs, torch.ones(5, 3)) and len(info) == 5
+
+
+def test_ego_index_and_three_players():
+    env = CountingEnv(2, n_players=3, ego_ind=1)
+    a, b = Recorder(1, 2), Recorder(4, 2)
+    env.add_partner_agent(a, player_num=0)
+    with pytest.raises(PlayerException):
+        env.add_partner_agent(b, player_num=1)      # the ego slot
+    # like the reference, the default partner lists are one shared list object
+    assert env.partners[0] is env.partners[1]
+    env2 = CountingEnv(2, n_players=3, ego_ind=1)
+    env2.partners = [[a], [b]]
+    env2.reset()
+    env2.step(torch.full((2, 1), 9))
+    assert env2.seen_actions[:, 0, 0].tolist() == [1, 9, 4]
+
+
+def test_resample_policies():
+    env = CountingEnv(1)
+    for v in range(3):
+        env.add_partner_agent(Recorder(v, 1))
+    ids = []
+    for _ in range(4):
+        env.reset()
+        ids.append(env.partnerids[0])
+    assert ids == [1, 2, 0, 1]                       # round robin for two players
+    with pytest.raises(PlayerException):
+        CountingEnv(1, n_players=3).set_resample_policy("robin")
+    with pytest.raises(PlayerException):
+        env.set_resample_policy("nonsense")
+    env.set_resample_policy("random")
+    np.random.seed(0)
+    env.reset()
+    assert 0 <= env.partnerids[0] < 3
+    env.set_partnerid(2)
+    assert env.partnerids == [2]
+    with pytest.raises(PlayerException):
+        VectorMultiAgentEnv.__init__(env, 1, torch.device("cpu"), partners=[[], []])
+
+
+def test_random_agent_and_spaces():
+    agent = RandomVectorAgent(lambda: torch.zeros(3, 1))
+    assert agent.get_action(None).shape == (3, 1) and agent.update(None, None) is None
+    d = spaces.Discrete(6)
+    assert d.n == 6 and 0 <= d.sample() < 6
+    mb = spaces.MultiBinary(np.array([5, 4, 26]))
+    assert tuple(mb.shape) == (5, 4, 26)
+    assert spaces.MultiBinary(658).shape == (658,)
+    box = spaces.Box(-np.ones(4, np.float32), np.ones(4, np.float32), dtype=np.float32)
+    assert box.shape == (4,) and box.sample().shape == (4,)
+
+
+def test_exec_mode_shim():
+    assert madrona.ExecMode.CPU is ExecMode.CPU and madrona.ExecMode.CUDA is ExecMode.CUDA
+    assert ExecMode.HIP is ExecMode.CUDA
