@@ -1,6 +1,6 @@
-// Overcooked world step for gfx950: one wavefront per world, whole step fused
-// in one kernel (action apply -> interactions -> movement/collisions -> pot
-// ticks -> horizon reset -> reward/done -> observation encode).
+// Overcooked world step for gfx950: the whole step fused in one kernel (action
+// apply -> interactions -> movement/collisions -> pot ticks -> horizon reset ->
+// reward/done -> observation encode), one wavefront per GROUP of worlds.
 //
 // Semantics follow the reference task graph
 //   /root/reference/src/overcooked_env/sim.cpp:498-537
@@ -8,15 +8,30 @@
 // widths of sim.hpp:59-184.  Nothing of Madrona's ECS/taskgraph is reproduced:
 // the 20 graph nodes and their per-cell scratch (past/current/future_player,
 // interacting_players) collapse into
-//   - a wave-uniform loop over the interacting players in ascending id, which is
-//     what the reference's four rank phases serialise to (sim.cpp:259-358),
+//   - a loop over the interacting players in ascending id, which is what the
+//     reference's four rank phases serialise to (sim.cpp:259-358),
 //   - a pairwise proposal test for the all-or-nothing collision rule
 //     (sim.cpp:363-426): same target or swapped cells => nobody moves,
 //   - a from-scratch observation encode (the reference updates rows in place
 //     and clears the player channels through past_player; every vacated cell is
 //     cleared, so the row is a pure function of the state).
 //
-// HBM layout, all world-major so a wave's loads and
+// Mapping (profiles/r01_a_*: the first version, one wave per world, moved exactly
+// the algorithmic 41 MB per launch but spent ~540 instructions per world, mostly
+// wave-uniform transition logic running on 64 lanes for one world, and was
+// issue/latency bound at 21 us).  Now a wave owns `wpw` consecutive worlds:
+//   load     all lanes copy the group's state slab HBM -> LDS (contiguous, coalesced)
+//   step     lane = world: the serial transition of its world on its LDS slice
+//   store    all lanes copy the slab back
+//   observe  all lanes: the group's wpw*P*C observation rows, 64 rows per pass:
+//            zero-fill an LDS tile, patch the few non-zero bytes of each row,
+//            stream the tile out with 16-byte stores (the group's rows are one
+//            contiguous range of HBM)
+// so the transition costs 1/wpw of a wave per world and the encode runs with all
+// lanes busy whatever the layout size.  wpw is picked on the host so that a launch
+// still has thousands of waves (wpw = 1 for very large layouts).
+//
+// HBM layout, all world-major so a group's loads and
 // stores are contiguous and a shard of worlds is one contiguous slab:
 //   cell_obj [N][C]  u32  name | onions<<8 | tomatoes<<16 | tick<<24
 //   players  [N][P]  2xu32 {pos | orientation<<8, held item (same packing)}
@@ -24,11 +39,9 @@
 //   action   [P][N]  i32  (the reference's exported shape, mgr.cpp:214-218)
 //   reward   [P][N]  i32, done [N] i32
 //   obs      [N][P][C][F] u8, F = 5P+16: one contiguous P*C*F block per world
-// Per-wave LDS: the cell objects, a cell->player map, the players' orientation
-// and held item, and a tile of up to 64 observation rows that is zero-filled,
-// patched with the few non-zero bytes, and streamed out with 16-byte stores.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -36,6 +49,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kRowsPerPass = 128;  // observation rows assembled per LDS tile
 
 enum : uint32_t { A_NORTH = 0, A_SOUTH = 1, A_EAST = 2, A_WEST = 3, A_STAY = 4, A_INTERACT = 5 };
 enum : uint32_t { T_AIR = 0, T_POT, T_COUNTER, T_ONION_SRC, T_TOMATO_SRC, T_DISH_SRC, T_SERVING };
@@ -48,17 +62,26 @@ constexpr uint32_t kConstTerrain = 0;    // 256 bytes
 constexpr uint32_t kConstTimes = 256;    // 16 bytes
 constexpr uint32_t kConstValues = 272;   // 16 bytes
 constexpr uint32_t kConstStart = 288;    // 64 bytes: start cell of each player
-constexpr uint32_t kConstBytes = 352;
+constexpr uint32_t kConstPots = 352;     // 256 bytes: cells holding a pot
+constexpr uint32_t kConstBytes = 608;
 
 struct StepParams {
     uint32_t num_worlds;
     uint32_t P, C, W, F;
     uint32_t rows;         // P*C
     uint32_t block_bytes;  // P*C*F
-    uint32_t inv_c;        // floor(2^32/C)+1: r / C == umulhi(r, inv_c) for r < 2^16
+    // x / d == umulhi(x, floor(2^32/d)+1) while x*d < 2^32 (checked on the host)
+    uint32_t inv_c, inv_p, inv_rows;
     uint32_t placement_rew, soup_pickup_rew;
-    uint32_t c_pad;        // C rounded up to 16
-    uint32_t p_pad;        // P rounded up to 2
+    uint32_t wpw;          // worlds per wave
+    uint32_t wpp;          // whole worlds per observation pass (0: a world spans several passes)
+    uint32_t num_pots;
+    uint32_t ablate;  // DEV ONLY
+    uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
+    // LDS slice strides, chosen odd in dwords so lane-per-world accesses spread over the banks
+    uint32_t cs, ps;       // cells / players, in dwords
+    uint32_t ab, cb;       // actions / cell->player map, in bytes
+    uint32_t off_pl, off_act, off_cur, off_flags, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
     const uint32_t *consts;  // kConstBytes, device
@@ -80,7 +103,75 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// Storing a row's 16 viewer-independent bytes into the LDS tile.  Rows are F = 5P+16 bytes
+// apart, so these 16 bytes are in general not 16-byte aligned, and a DS store off its natural
+// alignment is replayed (cdna_hip_programming.md G17; measured here: one misaligned b128 per
+// row cost 2.8 us of the step, four misaligned b32 8.5 us).  So the store is split into
+// naturally aligned pieces chosen by the (wave-uniform) alignment class of the address.
+// Written as asm so the compiler cannot fuse the pieces back into one misaligned b128.  LDS
+// operations of a wave execute in order, so later ds_reads of the same wave see these stores.
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)reinterpret_cast<uintptr_t>(p);  // low 32 bits of a shared pointer = LDS offset
+}
+
+__device__ __forceinline__ void lds_store_tail_a4(uint8_t *ptr, const uint4 &t)  // address % 4 == 0
+{
+    asm volatile("ds_write_b32 %0, %1\n\t"
+                 "ds_write_b32 %0, %2 offset:4\n\t"
+                 "ds_write_b32 %0, %3 offset:8\n\t"
+                 "ds_write_b32 %0, %4 offset:12"
+                 :
+                 : "v"(lds_addr(ptr)), "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w)
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_store_tail_a2(uint8_t *ptr, const uint4 &t)  // address % 4 == 2
+{
+    const uint32_t m1 = __builtin_amdgcn_alignbit(t.y, t.x, 16);
+    const uint32_t m2 = __builtin_amdgcn_alignbit(t.z, t.y, 16);
+    const uint32_t m3 = __builtin_amdgcn_alignbit(t.w, t.z, 16);
+    asm volatile("ds_write_b16 %0, %1\n\t"
+                 "ds_write_b32 %0, %2 offset:2\n\t"
+                 "ds_write_b32 %0, %3 offset:6\n\t"
+                 "ds_write_b32 %0, %4 offset:10\n\t"
+                 "ds_write_b16_d16_hi %0, %5 offset:14"
+                 :
+                 : "v"(lds_addr(ptr)), "v"(t.x), "v"(m1), "v"(m2), "v"(m3), "v"(t.w)
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_store_tail_h2(uint8_t *ptr, const uint4 &t)  // address % 2 == 0
+{
+    asm volatile("ds_write_b16 %0, %1\n\t"
+                 "ds_write_b16_d16_hi %0, %1 offset:2\n\t"
+                 "ds_write_b16 %0, %2 offset:4\n\t"
+                 "ds_write_b16_d16_hi %0, %2 offset:6\n\t"
+                 "ds_write_b16 %0, %3 offset:8\n\t"
+                 "ds_write_b16_d16_hi %0, %3 offset:10\n\t"
+                 "ds_write_b16 %0, %4 offset:12\n\t"
+                 "ds_write_b16_d16_hi %0, %4 offset:14"
+                 :
+                 : "v"(lds_addr(ptr)), "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w)
+                 : "memory");
+}
+
+__device__ __forceinline__ void lds_store_tail(uint8_t *ptr, const uint4 &t, uint32_t align_class)
+{
+    if (align_class == 0) {
+        lds_store_tail_a4(ptr, t);
+    } else if (align_class == 2) {
+        lds_store_tail_a2(ptr, t);
+    } else {  // odd address: bytes
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ptr[k] = (uint8_t)(t.x >> (8 * k));
+            ptr[4 + k] = (uint8_t)(t.y >> (8 * k));
+            ptr[8 + k] = (uint8_t)(t.z >> (8 * k));
+            ptr[12 + k] = (uint8_t)(t.w >> (8 * k));
+        }
+    }
+}
 
 __device__ __forceinline__ int32_t step_of(uint32_t dir, uint32_t width)
 {
@@ -93,188 +184,272 @@ __device__ __forceinline__ uint32_t recipe_of(uint32_t item)
     return ((kMaxIngredients + 1) * ((item >> 8) & 0xFF) + ((item >> 16) & 0xFF)) & 15u;
 }
 
+__device__ __forceinline__ uint32_t count_of(uint32_t item) { return (((item >> 8) & 0xFF) + ((item >> 16) & 0xFF)) & 0xFF; }
+
+// One world's transition, run by one lane on its LDS slice (sim.cpp:199-489).
+// pl[2q] = pos | ori<<8 (| proposed pos<<16 | proposed ori<<24 while moving), pl[2q+1] = held item.
+__device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
+                                              const uint8_t *s_values, const uint8_t *s_pots, uint32_t *obj,
+                                              uint32_t *pl, const uint8_t *act)
+{
+    const uint32_t P = p.P;
+    int32_t reward = 0;
+    // interactions, ascending player id (sim.cpp:208-358)
+    for (uint32_t q = 0; q < P; q++) {
+        if (act[q] != A_INTERACT) continue;
+        const uint32_t posori = pl[2 * q], held = pl[2 * q + 1];
+        const uint32_t tgt = (posori & 0xFF) + (uint32_t)step_of((posori >> 8) & 0xFF, p.W);
+        const uint32_t terr = s_terrain[tgt];
+        const uint32_t hname = held & 0xFF;
+        uint32_t new_held = held;
+        if (terr == T_COUNTER || terr == T_POT) {
+            const uint32_t there = obj[tgt];
+            const uint32_t oname = there & 0xFF;
+            uint32_t new_obj = there;
+            if (terr == T_COUNTER) {
+                if (hname != O_NONE && oname == O_NONE) {
+                    new_obj = held;
+                    new_held = kItemNone;
+                } else if (hname == O_NONE && oname != O_NONE) {
+                    new_held = there;
+                    new_obj = kItemNone;
+                }
+            } else {
+                const int32_t tick = (int8_t)(there >> 24);
+                if (hname == O_NONE) {
+                    // idle soup with something in it starts cooking
+                    if (oname == O_SOUP && tick < 0 && count_of(there) > 0) new_obj = there & 0x00FFFFFFu;
+                } else if (hname == O_DISH && oname == O_SOUP && tick >= 0 && tick >= (int32_t)s_times[recipe_of(there)]) {
+                    new_held = there;
+                    new_obj = kItemNone;
+                    reward += (int32_t)p.soup_pickup_rew;
+                } else if (hname == O_ONION || hname == O_TOMATO) {
+                    uint32_t soup = oname == O_NONE ? (O_SOUP | kItemNone) : there;
+                    if (!((int8_t)(soup >> 24) >= 0 || count_of(soup) == kMaxIngredients)) {
+                        soup += hname == O_ONION ? 0x100u : 0x10000u;
+                        new_held = kItemNone;
+                        reward += (int32_t)p.placement_rew;
+                    }
+                    new_obj = soup;
+                }
+            }
+            obj[tgt] = new_obj;
+        } else if (terr == T_ONION_SRC) {
+            if (hname == O_NONE) new_held = O_ONION | kItemNone;
+        } else if (terr == T_TOMATO_SRC) {
+            if (hname == O_NONE) new_held = O_TOMATO | kItemNone;
+        } else if (terr == T_DISH_SRC) {
+            if (hname == O_NONE) new_held = O_DISH | kItemNone;
+        } else if (terr == T_SERVING) {
+            if (hname == O_SOUP) {
+                reward += (int32_t)s_values[recipe_of(held)];
+                new_held = kItemNone;
+            }
+        }
+        pl[2 * q + 1] = new_held;
+    }
+
+    // movement proposals (sim.cpp:363-379)
+    for (uint32_t q = 0; q < P; q++) {
+        const uint32_t a = act[q], posori = pl[2 * q] & 0xFFFFu;
+        const uint32_t pos = posori & 0xFF, ori = posori >> 8;
+        uint32_t prop = pos, pori = ori;
+        if (a != A_INTERACT) {
+            const uint32_t np = pos + (uint32_t)step_of(a, p.W);
+            pori = a == A_STAY ? ori : a;
+            prop = s_terrain[np] != T_AIR ? pos : np;
+        }
+        pl[2 * q] = posori | (prop << 16) | (pori << 24);
+    }
+    // all-or-nothing collision rule (sim.cpp:383-426): same target, or two players swapping cells
+    bool blocked = false;
+    for (uint32_t a = 0; a + 1 < P; a++) {
+        const uint32_t ra = pl[2 * a];
+        const uint32_t pos_a = ra & 0xFF, prop_a = (ra >> 16) & 0xFF;
+        for (uint32_t b = a + 1; b < P; b++) {
+            const uint32_t rb = pl[2 * b];
+            const uint32_t pos_b = rb & 0xFF, prop_b = (rb >> 16) & 0xFF;
+            blocked |= (prop_a == prop_b) | ((prop_a == pos_b) & (pos_a == prop_b));
+        }
+    }
+    for (uint32_t q = 0; q < P; q++) {
+        const uint32_t r = pl[2 * q];
+        const uint32_t pos = blocked ? (r & 0xFF) : ((r >> 16) & 0xFF);
+        pl[2 * q] = pos | ((r >> 24) << 8);
+    }
+
+    // pots (sim.cpp:430-438): after the interactions, so a pot started now is already at 1
+    for (uint32_t k = 0; k < p.num_pots; k++) {
+        const uint32_t c = s_pots[k];
+        const uint32_t o = obj[c];
+        if ((o & 0xFF) == O_SOUP) {
+            const int32_t tick = (int8_t)(o >> 24);
+            if (tick >= 0 && tick < (int32_t)s_times[recipe_of(o)]) obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+        }
+    }
+    return reward;
+}
+
 template <bool kInit>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
-    const uint32_t wib = tid >> 6;
+    // wave-uniform values are forced into SGPRs so the address math around them is scalar
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
-    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = p.consts[tid];
-    __syncthreads();
+    // the constant block and the group's state slab are fetched together: one HBM/L2 latency
+    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
     const uint8_t *s_times = smem + kConstTimes;
     const uint8_t *s_values = smem + kConstValues;
     const uint8_t *s_start = smem + kConstStart;
+    const uint8_t *s_pots = smem + kConstPots;
 
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so
-    // give each XCD one contiguous range of worlds (neighbouring worlds share
-    // cache lines of every state array; keep them in one L2).
+    // give each XCD one contiguous range of worlds (neighbouring groups share
+    // cache lines of the state arrays and of the observation slab; keep them in one L2).
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t world = logical_block * kWavesPerBlock + wib;
-    if (world >= p.num_worlds) return;
+    const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
+    const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
 
+    // per-wave LDS: the group's state in the same dense order as in HBM
     uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
-    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
-    uint8_t *s_cur = wbase + p.c_pad * 4;
-    uint32_t *s_plr = reinterpret_cast<uint32_t *>(s_cur + p.c_pad);
-    uint8_t *s_tile = reinterpret_cast<uint8_t *>(s_plr + 2 * p.p_pad);
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);                 // [wpw][C]
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);       // [wpw][P][2]
+    uint8_t *s_act = wbase + p.off_act;                                    // [wpw][P]
+    uint8_t *s_cur = wbase + p.off_cur;                                    // [wpw][C] cell -> player
+    uint8_t *s_flags = wbase + p.off_flags;                                // [wpw]
+    uint4 *s_tail = reinterpret_cast<uint4 *>(wbase + p.off_tail);         // [wpw][C]
+    uint8_t *s_tile = wbase + p.off_tile;
 
     const uint32_t P = p.P, C = p.C, N = p.num_worlds;
-    const bool is_player = lane < P;
+    const uint32_t ncells = nw * C, nplayers = nw * P;
 
-    // ---------------- load ----------------
-    uint32_t posori = 0, held = kItemNone, act = A_STAY;
-    int32_t t = 0;
+    // ---------------- load: HBM slab -> LDS (straight copies) ----------------
     if (!kInit) {
-        for (uint32_t c = lane; c < C; c += kWave) s_obj[c] = p.cell_obj[(size_t)world * C + c];
-        if (is_player) {
-            const uint2 rec = p.players[(size_t)world * P + lane];
-            posori = rec.x;
-            held = rec.y;
-            const uint32_t a = (uint32_t)p.actions[(size_t)lane * N + world];
-            act = a <= A_INTERACT ? a : (uint32_t)A_STAY;  // values outside the enum are outside the contract
-        }
-        t = p.timestep[world];
-    }
-    uint32_t pos = posori & 0xFF, ori = (posori >> 8) & 0xFF;
-    int32_t reward = 0;
-    bool reset_now = kInit;
-
-    if (!kInit) {
-        wave_lds_sync();
-        // ---------------- interactions (sim.cpp:208-358) ----------------
-        const uint32_t facing = pos + (uint32_t)step_of(ori, p.W);
-        const uint32_t facing_terrain = is_player ? (uint32_t)s_terrain[facing] : (uint32_t)T_AIR;
-        unsigned long long todo = __ballot(is_player && act == A_INTERACT);
-        while (todo) {
-            const int q = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t tgt = (uint32_t)__builtin_amdgcn_readlane((int)facing, q);
-            const uint32_t terr = (uint32_t)__builtin_amdgcn_readlane((int)facing_terrain, q);
-            const uint32_t q_held = (uint32_t)__builtin_amdgcn_readlane((int)held, q);
-            const uint32_t hname = q_held & 0xFF;
-            uint32_t new_held = q_held;
-            if (terr == T_COUNTER || terr == T_POT) {
-                const uint32_t obj = rfl(s_obj[tgt]);
-                const uint32_t oname = obj & 0xFF;
-                uint32_t new_obj = obj;
-                if (terr == T_COUNTER) {
-                    if (hname != O_NONE && oname == O_NONE) {
-                        new_obj = q_held;
-                        new_held = kItemNone;
-                    } else if (hname == O_NONE && oname != O_NONE) {
-                        new_held = obj;
-                        new_obj = kItemNone;
-                    }
-                } else {
-                    const int32_t tick = (int8_t)(obj >> 24);
-                    const uint32_t count = (((obj >> 8) & 0xFF) + ((obj >> 16) & 0xFF)) & 0xFF;
-                    if (hname == O_NONE) {
-                        // idle soup with something in it starts cooking
-                        if (oname == O_SOUP && tick < 0 && count > 0) new_obj = obj & 0x00FFFFFFu;
-                    } else if (hname == O_DISH && oname == O_SOUP && tick >= 0 &&
-                               tick >= (int32_t)rfl(s_times[recipe_of(obj)])) {
-                        new_held = obj;
-                        new_obj = kItemNone;
-                        reward += (int32_t)p.soup_pickup_rew;
-                    } else if (hname == O_ONION || hname == O_TOMATO) {
-                        uint32_t soup = oname == O_NONE ? (O_SOUP | kItemNone) : obj;
-                        const int32_t stick = (int8_t)(soup >> 24);
-                        const uint32_t scount = (((soup >> 8) & 0xFF) + ((soup >> 16) & 0xFF)) & 0xFF;
-                        if (!(stick >= 0 || scount == kMaxIngredients)) {
-                            soup += hname == O_ONION ? 0x100u : 0x10000u;
-                            new_held = kItemNone;
-                            reward += (int32_t)p.placement_rew;
-                        }
-                        new_obj = soup;
-                    }
-                }
-                if (new_obj != obj) s_obj[tgt] = new_obj;
-                wave_lds_sync();
-            } else if (terr == T_ONION_SRC) {
-                if (hname == O_NONE) new_held = O_ONION | kItemNone;
-            } else if (terr == T_TOMATO_SRC) {
-                if (hname == O_NONE) new_held = O_TOMATO | kItemNone;
-            } else if (terr == T_DISH_SRC) {
-                if (hname == O_NONE) new_held = O_DISH | kItemNone;
-            } else if (terr == T_SERVING) {
-                if (hname == O_SOUP) {
-                    reward += (int32_t)rfl(s_values[recipe_of(q_held)]);
-                    new_held = kItemNone;
-                }
+        const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
+        const uint2 *g_pl = p.players + (size_t)w0 * P;
+        for (uint32_t i = lane; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
+        if (lane < nw) {
+            for (uint32_t q = 0; q < P; q++) {
+                const uint32_t a = (uint32_t)p.actions[(size_t)q * N + w0 + lane];
+                s_act[lane * P + q] = (uint8_t)(a <= A_INTERACT ? a : (uint32_t)A_STAY);  // outside the enum = outside the contract
             }
-            if ((int)lane == q) held = new_held;
-        }
-
-        // ---------------- movement (sim.cpp:363-426) ----------------
-        uint32_t prop = pos, pori = ori;
-        if (is_player && act != A_INTERACT) {
-            const uint32_t np = pos + (uint32_t)step_of(act, p.W);
-            pori = act == A_STAY ? ori : act;
-            prop = s_terrain[np] != T_AIR ? pos : np;
-        }
-        bool conflict = false;
-        for (uint32_t q = 0; q < P; q++) {
-            const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)prop, (int)q);
-            const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)q);
-            conflict |= (q != lane) & ((prop == pq) | ((prop == oq) & (pos == pq)));
-        }
-        const bool blocked = __ballot(is_player && conflict) != 0ull;
-        if (!blocked) pos = prop;
-        ori = pori;
-
-        // ---------------- horizon (sim.cpp:485-489) ----------------
-        t += 1;
-        reset_now = (int64_t)t >= p.horizon;
-    }
-
-    // ---------------- reset (sim.cpp:441-482) ----------------
-    if (reset_now) {
-        t = 0;
-        if (is_player) {
-            pos = s_start[lane];
-            ori = A_NORTH;
-            held = kItemNone;
         }
     }
+    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+    __syncthreads();
+    if (nw == 0) return;
 
-    // ---------------- pots (sim.cpp:430-438), object reset, state write-back ----------------
-    for (uint32_t c = lane; c < C; c += kWave) {
-        uint32_t o = kInit ? kItemNone : s_obj[c];
-        if (!kInit && s_terrain[c] == T_POT && (o & 0xFF) == O_SOUP) {
-            const int32_t tick = (int8_t)(o >> 24);
-            if (tick >= 0 && tick < (int32_t)s_times[recipe_of(o)]) o = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+    // ---------------- step: lane = world ----------------
+    if (lane < nw) {
+        uint32_t *obj = s_obj + lane * C;
+        uint32_t *pl = s_pl + lane * 2 * P;
+        const uint32_t world = w0 + lane;
+        int32_t reward = 0, t = 0;
+        bool reset_now = kInit;
+        if (!kInit) {
+            if (!(p.ablate & 4)) reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
+            // horizon (sim.cpp:485-489)
+            t = p.timestep[world] + 1;
+            reset_now = (int64_t)t >= p.horizon;
         }
-        if (reset_now) o = kItemNone;
-        s_obj[c] = o;
-        s_cur[c] = 0xFF;
-        p.cell_obj[(size_t)world * C + c] = o;
-    }
-    if (is_player) {
-        p.players[(size_t)world * P + lane] = make_uint2(pos | (ori << 8), held);
-        p.reward[(size_t)lane * N + world] = reward;
-    }
-    if (lane == 0) {
+        // reset (sim.cpp:441-482)
+        if (reset_now) {
+            t = 0;
+            for (uint32_t c = 0; c < C; c++) obj[c] = kItemNone;
+            for (uint32_t q = 0; q < P; q++) {
+                pl[2 * q] = (uint32_t)s_start[q] | (A_NORTH << 8);
+                pl[2 * q + 1] = kItemNone;
+            }
+        }
+        for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = reward;
         p.timestep[world] = t;
         p.done[world] = kInit ? 0 : (int32_t)reset_now;
+        s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;  // urgency channel (sim.cpp:79-83)
     }
+    // cell -> player map for the encode
+    for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
     wave_lds_sync();
-    if (is_player) {
-        s_cur[pos] = (uint8_t)lane;
-        s_plr[2 * lane] = ori;
-        s_plr[2 * lane + 1] = held;
+    if (lane < nw)
+        for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
+    wave_lds_sync();
+
+    // ---------------- store: LDS -> HBM slab ----------------
+    {
+        uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
+        uint2 *g_pl = p.players + (size_t)w0 * P;
+        for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
+    }
+
+    // ---------------- observe (sim.cpp:68-167, 642-645) ----------------
+    // A row is [5P viewer-relative player channels][16 viewer-independent bytes].  The 16 bytes
+    // (terrain one-hot, pot / soup / item channels incl. what the player standing there holds,
+    // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
+    const uint32_t F = p.F, shift = 5 * P;
+    for (uint32_t i = lane; i < ncells; i += kWave) {
+        const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+        const uint32_t terr = s_terrain[c];
+        const uint32_t o = s_obj[i];
+        const uint32_t who = s_cur[i];
+        const uint32_t urgent = s_flags[l];
+        const uint32_t h = who != 0xFF ? s_pl[(__umul24(l, P) + who) * 2 + 1] : kItemNone;
+        const int32_t need = (int32_t)s_times[recipe_of(o)];
+        const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, tom = (o >> 16) & 0xFF;
+        const int32_t tick = (int8_t)(o >> 24);
+        const uint32_t hname = h & 0xFF;
+        const bool is_soup = oname == O_SOUP, in_pot = terr == T_POT;
+        const bool idle = is_soup & in_pot & (tick < 0);
+        const bool hot = is_soup & in_pot & (tick >= 0);
+        const bool plated = is_soup & !in_pot;
+        const bool hsoup = hname == O_SOUP;  // a soup in hand overrides the cell's soup channels
+        const uint32_t idle_on = idle ? on : 0u, idle_tom = idle ? tom : 0u;
+        const uint32_t soup_on = hsoup ? (h >> 8) & 0xFF : ((hot | plated) ? on : 0u);
+        const uint32_t soup_tom = hsoup ? (h >> 16) & 0xFF : ((hot | plated) ? tom : 0u);
+        const uint32_t remaining = (hot & !hsoup) ? (uint32_t)(need - tick) & 0xFF : 0u;
+        const uint32_t ready = (hsoup | plated | (hot & (tick >= need))) ? 1u : 0u;
+        const uint32_t dish = ((oname == O_DISH) | (hname == O_DISH)) ? 1u : 0u;
+        const uint32_t onion = ((oname == O_ONION) | (hname == O_ONION)) ? 1u : 0u;
+        const uint32_t tomato = ((oname == O_TOMATO) | (hname == O_TOMATO)) ? 1u : 0u;
+        const uint32_t tbit = terr == T_AIR ? 0u : 1u;
+        const uint32_t tsh = ((terr - 1u) & 3u) * 8u;
+        uint4 t;
+        t.x = (terr >= 1 && terr <= 4) ? (tbit << tsh) : 0u;
+        t.y = ((terr >= 5) ? (tbit << tsh) : 0u) | (idle_on << 16) | (idle_tom << 24);
+        t.z = soup_on | (soup_tom << 8) | (remaining << 16) | (ready << 24);
+        t.w = dish | (onion << 8) | (tomato << 16) | ((urgent ? 1u : 0u) << 24);
+        s_tail[i] = t;
     }
     wave_lds_sync();
 
-    // ---------------- observation (sim.cpp:68-167, 642-645) ----------------
-    const bool urgent = p.horizon - (int64_t)t < 40;
-    const uint32_t F = p.F, shift = 5 * P;
-    uint8_t *gobs = p.obs + (size_t)world * p.block_bytes;
-    for (uint32_t r0 = 0; r0 < p.rows; r0 += kWave) {
-        const uint32_t nrows = min((uint32_t)kWave, p.rows - r0);
+    // Rows are assembled kRowsPerPass at a time in an LDS tile and streamed out.  When a world
+    // has no more rows than a tile, a pass covers whole worlds (p.wpp of them), so which
+    // (world-in-pass, viewer, cell) a lane's rows are is the same in every pass and is worked
+    // out once, outside the loop; larger layouts take the generic per-pass indexing.
+    // Lane i assembles rows 2i and 2i+1 of the tile: each of the two has one alignment class
+    // for the whole wave (F is even for even P), which picks the LDS store sequence.
+    constexpr uint32_t kRowsPerLane = kRowsPerPass / kWave;
+    const uint32_t rows = p.rows;
+    const uint32_t pass_rows = p.wpp ? p.wpp * rows : (uint32_t)kRowsPerPass;
+    uint32_t k_wl[kRowsPerLane], k_viewer[kRowsPerLane], k_c[kRowsPerLane];
+#pragma unroll
+    for (uint32_t j = 0; j < kRowsPerLane; j++) {
+        const uint32_t tr = lane * kRowsPerLane + j;
+        const uint32_t wl = __umulhi(tr, p.inv_rows), r = tr - __umul24(wl, rows);
+        k_wl[j] = wl;
+        k_viewer[j] = __umulhi(r, p.inv_c);
+        k_c[j] = r - __umul24(k_viewer[j], C);
+    }
+    const uint32_t total_rows = nw * rows;
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    uint32_t first_world = 0;  // of the current pass (aligned passes only)
+    for (uint32_t r0 = 0; r0 < ((p.ablate & 8) ? 0u : total_rows); r0 += pass_rows, first_world += p.wpp) {
+        const uint32_t nrows = min(pass_rows, total_rows - r0);
         const uint32_t nbytes = nrows * F;
         uint8_t *g = gobs + (size_t)r0 * F;
         // keep LDS and global addresses congruent mod 16 so aligned 16-byte
@@ -286,70 +461,36 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
 
-        if (lane < nrows) {
-            const uint32_t r = r0 + lane;
-            const uint32_t viewer = __umulhi(r, p.inv_c);
-            const uint32_t c = r - viewer * C;
-            uint8_t *row = tile + lane * F;
-            const uint32_t terr = s_terrain[c];
-            const uint32_t o = s_obj[c];
-            const uint32_t who = s_cur[c];
-
-            if (terr != T_AIR) row[shift + terr - 1] = 1;
-            if (urgent) row[shift + 15] = 1;
-
-            // channels shift+6 .. shift+14, computed branch-free then stored
-            const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, tom = (o >> 16) & 0xFF;
-            const int32_t tick = (int8_t)(o >> 24);
-            uint32_t idle_on = 0, idle_tom = 0, soup_on = 0, soup_tom = 0, remaining = 0, ready = 0;
-            uint32_t dish = oname == O_DISH, onion = oname == O_ONION, tomato = oname == O_TOMATO;
-            if (oname == O_SOUP) {
-                if (terr == T_POT) {
-                    if (tick < 0) {
-                        idle_on = on;
-                        idle_tom = tom;
-                    } else {
-                        const int32_t need = (int32_t)s_times[recipe_of(o)];
-                        soup_on = on;
-                        soup_tom = tom;
-                        remaining = (uint32_t)(need - tick) & 0xFF;
-                        ready = tick >= need;
-                    }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            const uint32_t tr = lane * kRowsPerLane + j;
+            if (tr < nrows && !(p.ablate & 1)) {
+                uint32_t l, viewer, c;
+                if (p.wpp) {
+                    l = first_world + k_wl[j];
+                    viewer = k_viewer[j];
+                    c = k_c[j];
                 } else {
-                    soup_on = on;
-                    soup_tom = tom;
-                    ready = 1;
+                    const uint32_t gr = r0 + tr;
+                    l = __umulhi(gr, p.inv_rows);
+                    const uint32_t r = gr - __umul24(l, rows);
+                    viewer = __umulhi(r, p.inv_c);
+                    c = r - __umul24(viewer, C);
+                }
+                const uint32_t cell = __umul24(l, C) + c;
+                uint8_t *row = tile + __umul24(tr, F);
+                const uint4 t = s_tail[cell];
+                const uint32_t who = s_cur[cell];
+                // alignment class of row tr's tail; wave-uniform when F is even (tr has the parity of j)
+                const uint32_t cls = p.tail_even ? ((mis + j * F + shift) & 3u) : 1u;
+                lds_store_tail(row + shift, t, cls);
+                // the viewer-relative player channels: two bytes, only on occupied cells
+                if (who != 0xFF) {
+                    const uint32_t rel = who == viewer ? 0u : (who < viewer ? who + 1u : who);
+                    row[rel] = 1;
+                    row[P + 4 * rel + ((s_pl[(__umul24(l, P) + who) * 2] >> 8) & 0xFF)] = 1;
                 }
             }
-            if (who != 0xFF) {
-                const uint32_t rel = who == viewer ? 0u : (who < viewer ? who + 1u : who);
-                const uint32_t w_ori = s_plr[2 * who], w_held = s_plr[2 * who + 1];
-                row[rel] = 1;
-                row[P + 4 * rel + w_ori] = 1;
-                const uint32_t hname = w_held & 0xFF;
-                if (hname == O_SOUP) {
-                    soup_on = (w_held >> 8) & 0xFF;
-                    soup_tom = (w_held >> 16) & 0xFF;
-                    remaining = 0;
-                    ready = 1;
-                } else if (hname == O_DISH) {
-                    dish = 1;
-                } else if (hname == O_ONION) {
-                    onion = 1;
-                } else if (hname == O_TOMATO) {
-                    tomato = 1;
-                }
-            }
-            uint8_t *tail = row + shift + 6;
-            tail[0] = (uint8_t)idle_on;
-            tail[1] = (uint8_t)idle_tom;
-            tail[2] = (uint8_t)soup_on;
-            tail[3] = (uint8_t)soup_tom;
-            tail[4] = (uint8_t)remaining;
-            tail[5] = (uint8_t)ready;
-            tail[6] = (uint8_t)dish;
-            tail[7] = (uint8_t)onion;
-            tail[8] = (uint8_t)tomato;
         }
         wave_lds_sync();
 
@@ -359,7 +500,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint32_t body = (nbytes - head) >> 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
         uint4 *dst = reinterpret_cast<uint4 *>(g + head);
-        for (uint32_t k = lane; k < body; k += kWave) dst[k] = src[k];
+        if (!(p.ablate & 2)) for (uint32_t k = lane; k < body; k += kWave) dst[k] = src[k];
         const uint32_t done_bytes = head + (body << 4);
         if (lane < nbytes - done_bytes) g[done_bytes + lane] = tile[done_bytes + lane];
         wave_lds_sync();
@@ -484,6 +625,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
     const int64_t C = H * W;
     alignas(4) uint8_t consts[kConstBytes];
     memset(consts, 0, sizeof(consts));
+    uint32_t num_pots = 0;
     for (int64_t c = 0; c < C; c++) {
         const int64_t t = cfg->terrain[c];
         if (t < 0 || t > 6) {
@@ -498,6 +640,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             throw HipError{MRL_ERR_INVALID};
         }
         consts[kConstTerrain + c] = (uint8_t)t;
+        if (t == T_POT) consts[kConstPots + num_pots++] = (uint8_t)c;
     }
     for (int r = 0; r < 16; r++) {
         consts[kConstTimes + r] = (uint8_t)cfg->recipe_times[r];
@@ -533,13 +676,46 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.placement_rew = (uint8_t)cfg->placement_in_pot_rew;  // uint8 like WorldState (sim.hpp:95-97)
         a.soup_pickup_rew = (uint8_t)cfg->soup_pickup_rew;
         a.horizon = cfg->horizon;
-        a.c_pad = (a.C + 15u) & ~15u;
-        a.p_pad = (a.P + 1u) & ~1u;
-        const uint32_t tile_rows = a.rows < (uint32_t)kWave ? a.rows : (uint32_t)kWave;
-        const uint32_t tile_bytes = ((tile_rows * a.F + 15u) & ~15u) + 32u;
-        a.lds_wave_stride = a.c_pad * 4 + a.c_pad + a.p_pad * 8 + tile_bytes;
-        sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
-        const uint32_t blocks = (N + kWavesPerBlock - 1) / kWavesPerBlock;
+        a.num_pots = num_pots;
+        a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
+        a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;
+        a.ablate = getenv("MRL_ABLATE") ? (uint32_t)atoi(getenv("MRL_ABLATE")) : 0u;
+        a.inv_p = P == 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)P) + 1u;  // x/1: umulhi(x, 2^32-1) == x-1 for x>0; handled in-kernel
+        a.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)a.rows) + 1u;
+        const uint32_t tile_bytes = (((uint32_t)kRowsPerPass * a.F + 15u) & ~15u) + 32u;
+        auto layout = [&](uint32_t wpw) {
+            auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+            a.wpw = wpw;
+            a.off_pl = up16(wpw * a.C * 4);
+            a.off_act = a.off_pl + up16(wpw * a.P * 8);
+            a.off_cur = a.off_act + up16(wpw * a.P);
+            a.off_flags = a.off_cur + up16(wpw * a.C);
+            a.off_tail = a.off_flags + up16(wpw);
+            a.off_tile = a.off_tail + wpw * a.C * 16;
+            a.lds_wave_stride = a.off_tile + tile_bytes;
+            return kConstBytes + kWavesPerBlock * a.lds_wave_stride;
+        };
+        // worlds per wave: as many as keep >= 4096 waves in the launch, fit 40 KB of LDS per
+        // workgroup (>= 4 workgroups per CU) and keep the reciprocal divisions exact
+        uint32_t wpw = 64;
+        if (const char *env = getenv("MRL_OVERCOOKED_WPW")) {
+            wpw = (uint32_t)atoi(env);
+            if (wpw < 1 || wpw > 64) wpw = 1;
+        } else {
+            while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
+        }
+        while (wpw > 1 && (layout(wpw) > 40960 || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
+                           (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
+            wpw >>= 1;
+        sim->lds_bytes = layout(wpw);
+        if (sim->lds_bytes > 65536)
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+        if (sim->lds_bytes > 65536)
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+        const uint32_t waves = (N + wpw - 1) / wpw;
+        const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
 
         uint32_t *d_consts = sim->arena.alloc<uint32_t>(kConstBytes / 4, false);
