@@ -96,11 +96,14 @@ struct StepParams {
 
 __device__ __forceinline__ void wave_lds_sync()
 {
-    // LDS instructions of one wave execute in issue order; this only stops the
-    // compiler from moving LDS accesses across the point.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // Cross-lane hand-off through LDS inside ONE wave: DS instructions of a wave are executed
+    // in issue order, so a later ds_read sees an earlier ds_write of another lane without any
+    // wait.  All that is needed is that the compiler keeps the order -- a compiler-only
+    // barrier.  (A wavefront-scope release/acquire fence also does that, but hipcc lowers it
+    // with s_waitcnt vmcnt(0): the wave then sits out the full latency of its state stores
+    // before it starts the observation passes.)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 // Storing a row's 16 viewer-independent bytes into the LDS tile.  Rows are F = 5P+16 bytes

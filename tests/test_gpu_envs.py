@@ -156,3 +156,31 @@ def test_sharded_wrapper_single_rank_equals_plain(hip_lib):
     local = ov.sim.observation_world_major_tensor().to_torch()
     assert ov.gather(local, 0) is local
     plain.close()
+
+
+def test_reference_style_scatter_on_hanabi_exports(hip_lib):
+    """What the reference's generic wrapper does with a simulator's exports
+    (pantheonrl_extension/vectorenv.py:283-293,306-329: clone, then index_put
+    through the agent/world id tensors, then slice) must work on this engine's
+    strided views and give the same tensors as reading them directly."""
+    n = 97
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                          max_information_tokens=8, max_life_tokens=3)
+    static_obs = sim.observation_tensor().to_torch()
+    static_state = sim.agent_state_tensor().to_torch()
+    static_mask = sim.action_mask_tensor().to_torch()
+    wid = sim.world_id_tensor().to_torch().to(torch.long)
+    aid = sim.agent_id_tensor().to_torch().to(torch.long)
+    scattered_obs = static_obs.detach().clone()
+    scattered_state = static_state.detach().clone()
+    assert scattered_obs.is_contiguous() and scattered_obs.shape == (2, n, 658)
+    act = sim.action_tensor().to_torch()
+    for _ in range(25):
+        actions = (torch.rand(static_mask.shape, device="cuda") * static_mask).argmax(-1, keepdim=True)
+        act.copy_(actions[aid, wid, :])          # the reference's action gather
+        sim.step()
+        scattered_obs[aid, wid, :] = static_obs
+        scattered_state[aid, wid, :] = static_state
+        assert torch.equal(scattered_obs, static_obs) and torch.equal(scattered_state, static_state)
+        assert torch.equal(scattered_obs[1, :, :658].to("cpu"), static_obs[1].cpu())
+    sim.close()
