@@ -152,6 +152,15 @@ def main():
     kernel_ms_avg = ev0.elapsed_time(ev1) / k_launch
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
+        # inside this process); only reported when they were taken on this exact workload
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "overcooked_step_traffic.json")))
+            if pmc["layout"] == args.layout and pmc["worlds"] == n and pmc["kernel"] == sim.kernel_name:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         bytes_per_launch = sim.bytes_per_world_step * n
         achieved = bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
         out = {
@@ -171,7 +180,7 @@ def main():
                                    f"uniform random actions (pre-sampled pool of {args.pool}, resident in HBM)",
                        "worlds_per_gpu": n, "obs_gather": bool(gathered is not None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": sim.kernel_name, "kernel_us_avg": kernel_ms_avg * 1e3,
                          "bytes_per_launch": bytes_per_launch, "launches_timed": k_launch},
         }

@@ -14,7 +14,8 @@ import subprocess
 import torch  # noqa: F401
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmrl_envs.so")
+# MRL_ENVS_LIB: load another build of the same ABI (the diagnostic build of `make diag`)
+LIB_PATH = os.environ.get("MRL_ENVS_LIB") or os.path.join(_PKG, "libmrl_envs.so")
 CSRC = os.path.join(_PKG, "csrc")
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "mrl_envs.h")
 

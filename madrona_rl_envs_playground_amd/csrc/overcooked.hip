@@ -41,6 +41,7 @@
 //   obs      [N][P][C][F] u8, F = 5P+16: one contiguous P*C*F block per world
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -76,11 +77,12 @@ struct StepParams {
     uint32_t wpw;          // worlds per wave
     uint32_t wpp;          // whole worlds per observation pass (0: a world spans several passes)
     uint32_t num_pots;
-    uint32_t ablate;  // DEV ONLY
+#ifdef MRL_DIAG
+    uint32_t ablate;             // diagnostic build only: phase ablation mask
+    unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps
+#endif
+    uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
-    // LDS slice strides, chosen odd in dwords so lane-per-world accesses spread over the banks
-    uint32_t cs, ps;       // cells / players, in dwords
-    uint32_t ab, cb;       // actions / cell->player map, in bytes
     uint32_t off_pl, off_act, off_cur, off_flags, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
@@ -144,21 +146,6 @@ __device__ __forceinline__ void lds_store_tail_a2(uint8_t *ptr, const uint4 &t) 
                  : "memory");
 }
 
-__device__ __forceinline__ void lds_store_tail_h2(uint8_t *ptr, const uint4 &t)  // address % 2 == 0
-{
-    asm volatile("ds_write_b16 %0, %1\n\t"
-                 "ds_write_b16_d16_hi %0, %1 offset:2\n\t"
-                 "ds_write_b16 %0, %2 offset:4\n\t"
-                 "ds_write_b16_d16_hi %0, %2 offset:6\n\t"
-                 "ds_write_b16 %0, %3 offset:8\n\t"
-                 "ds_write_b16_d16_hi %0, %3 offset:10\n\t"
-                 "ds_write_b16 %0, %4 offset:12\n\t"
-                 "ds_write_b16_d16_hi %0, %4 offset:14"
-                 :
-                 : "v"(lds_addr(ptr)), "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w)
-                 : "memory");
-}
-
 __device__ __forceinline__ void lds_store_tail(uint8_t *ptr, const uint4 &t, uint32_t align_class)
 {
     if (align_class == 0) {
@@ -189,6 +176,116 @@ __device__ __forceinline__ uint32_t recipe_of(uint32_t item)
 
 __device__ __forceinline__ uint32_t count_of(uint32_t item) { return (((item >> 8) & 0xFF) + ((item >> 16) & 0xFF)) & 0xFF; }
 
+// The counter/pot/source/serving interaction of one player (sim.cpp:208-358), shared by the
+// generic and the register-resident transition.  `there` is the object on the faced cell
+// (only read for counters and pots); returns the player's new held item.
+__device__ __forceinline__ uint32_t interact(const StepParams &p, const uint8_t *s_times, const uint8_t *s_values,
+                                             uint32_t terr, uint32_t held, uint32_t &there, int32_t &reward)
+{
+    // Straight-line selects instead of the if/else ladder of sim.cpp:229-253,299-335: lanes of
+    // one wave are different worlds taking different branches, so a ladder costs the sum of
+    // all its arms anyway; this form is shorter than that sum.
+    const uint32_t hname = held & 0xFF, oname = there & 0xFF;
+    const int32_t tick = (int8_t)(there >> 24);
+    const int32_t need = (int32_t)s_times[recipe_of(there)];
+    const int32_t value = (int32_t)s_values[recipe_of(held)];
+    const bool counter = terr == T_COUNTER, pot = terr == T_POT;
+    const bool empty_handed = hname == O_NONE, nothing_there = oname == O_NONE, soup_there = oname == O_SOUP;
+    // counter: put down / pick up
+    const bool put = counter & !empty_handed & nothing_there;
+    const bool take = counter & empty_handed & !nothing_there;
+    // pot: start cooking / plate a ready soup / add an ingredient
+    const bool start = pot & empty_handed & soup_there & (tick < 0) & (count_of(there) > 0);
+    const bool plate = pot & (hname == O_DISH) & soup_there & (tick >= 0) & (tick >= need);
+    const bool ingredient = pot & ((hname == O_ONION) | (hname == O_TOMATO));
+    const uint32_t soup = nothing_there ? (O_SOUP | kItemNone) : there;
+    const bool add = ingredient & !(((int8_t)(soup >> 24) >= 0) | (count_of(soup) == kMaxIngredients));
+    // sources and serving window
+    const bool source = (terr == T_ONION_SRC) | (terr == T_TOMATO_SRC) | (terr == T_DISH_SRC);
+    const uint32_t fresh = (terr == T_ONION_SRC ? (uint32_t)O_ONION : terr == T_TOMATO_SRC ? (uint32_t)O_TOMATO : (uint32_t)O_DISH) | kItemNone;
+    const bool grab = source & empty_handed;
+    const bool serve = (terr == T_SERVING) & (hname == O_SOUP);
+
+    uint32_t new_there = there;
+    new_there = start ? (there & 0x00FFFFFFu) : new_there;
+    new_there = ingredient ? (add ? soup + (hname == O_ONION ? 0x100u : 0x10000u) : soup) : new_there;
+    new_there = put ? held : new_there;
+    new_there = (take | plate) ? kItemNone : new_there;
+    uint32_t new_held = held;
+    new_held = (take | plate) ? there : new_held;
+    new_held = grab ? fresh : new_held;
+    new_held = (put | add | serve) ? kItemNone : new_held;
+    reward += (plate ? (int32_t)p.soup_pickup_rew : 0) + (add ? (int32_t)p.placement_rew : 0) + (serve ? value : 0);
+    there = new_there;
+    return new_held;
+}
+
+// Transition with a compile-time player count: the players live in registers, every LDS read
+// that does not depend on an earlier write (player records, actions, terrain of the faced and
+// of the target cells) is issued up front, and only the faced cells' objects are touched in
+// order.  Same semantics as `transition` below.
+template <int kP>
+__device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
+                                                    const uint8_t *s_values, const uint8_t *s_pots, uint32_t *obj,
+                                                    uint32_t *pl, const uint8_t *act)
+{
+    uint32_t posori[kP], held[kP], a[kP], tgt[kP], terr[kP], ahead[kP];
+#pragma unroll
+    for (int q = 0; q < kP; q++) {
+        posori[q] = pl[2 * q] & 0xFFFFu;
+        held[q] = pl[2 * q + 1];
+        a[q] = act[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kP; q++) {
+        const uint32_t pos = posori[q] & 0xFF, ori = posori[q] >> 8;
+        tgt[q] = pos + (uint32_t)step_of(ori, p.W);
+        terr[q] = s_terrain[tgt[q]];
+        ahead[q] = s_terrain[pos + (uint32_t)step_of(a[q], p.W)];  // STAY / INTERACT: own cell (AIR)
+    }
+    int32_t reward = 0;
+#pragma unroll
+    for (int q = 0; q < kP; q++) {
+        if (a[q] != A_INTERACT) continue;
+        const bool touches = terr[q] == T_COUNTER || terr[q] == T_POT;
+        uint32_t there = touches ? obj[tgt[q]] : kItemNone;
+        const uint32_t before = there;
+        held[q] = interact(p, s_times, s_values, terr[q], held[q], there, reward);
+        if (touches && there != before) obj[tgt[q]] = there;
+    }
+    uint32_t pos[kP], prop[kP], pori[kP];
+#pragma unroll
+    for (int q = 0; q < kP; q++) {
+        pos[q] = posori[q] & 0xFF;
+        const uint32_t ori = posori[q] >> 8;
+        prop[q] = pos[q];
+        pori[q] = ori;
+        if (a[q] != A_INTERACT) {
+            pori[q] = a[q] == A_STAY ? ori : a[q];
+            prop[q] = ahead[q] != T_AIR ? pos[q] : pos[q] + (uint32_t)step_of(a[q], p.W);
+        }
+    }
+    bool blocked = false;
+#pragma unroll
+    for (int x = 0; x < kP; x++)
+#pragma unroll
+        for (int y = x + 1; y < kP; y++) blocked |= (prop[x] == prop[y]) | ((prop[x] == pos[y]) & (pos[x] == prop[y]));
+#pragma unroll
+    for (int q = 0; q < kP; q++) {
+        pl[2 * q] = (blocked ? pos[q] : prop[q]) | (pori[q] << 8);
+        pl[2 * q + 1] = held[q];
+    }
+    for (uint32_t k = 0; k < p.num_pots; k++) {
+        const uint32_t c = s_pots[k];
+        const uint32_t o = obj[c];
+        if ((o & 0xFF) == O_SOUP) {
+            const int32_t tick = (int8_t)(o >> 24);
+            if (tick >= 0 && tick < (int32_t)s_times[recipe_of(o)]) obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+        }
+    }
+    return reward;
+}
+
 // One world's transition, run by one lane on its LDS slice (sim.cpp:199-489).
 // pl[2q] = pos | ori<<8 (| proposed pos<<16 | proposed ori<<24 while moving), pl[2q+1] = held item.
 __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
@@ -200,56 +297,14 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
     // interactions, ascending player id (sim.cpp:208-358)
     for (uint32_t q = 0; q < P; q++) {
         if (act[q] != A_INTERACT) continue;
-        const uint32_t posori = pl[2 * q], held = pl[2 * q + 1];
+        const uint32_t posori = pl[2 * q];
         const uint32_t tgt = (posori & 0xFF) + (uint32_t)step_of((posori >> 8) & 0xFF, p.W);
         const uint32_t terr = s_terrain[tgt];
-        const uint32_t hname = held & 0xFF;
-        uint32_t new_held = held;
-        if (terr == T_COUNTER || terr == T_POT) {
-            const uint32_t there = obj[tgt];
-            const uint32_t oname = there & 0xFF;
-            uint32_t new_obj = there;
-            if (terr == T_COUNTER) {
-                if (hname != O_NONE && oname == O_NONE) {
-                    new_obj = held;
-                    new_held = kItemNone;
-                } else if (hname == O_NONE && oname != O_NONE) {
-                    new_held = there;
-                    new_obj = kItemNone;
-                }
-            } else {
-                const int32_t tick = (int8_t)(there >> 24);
-                if (hname == O_NONE) {
-                    // idle soup with something in it starts cooking
-                    if (oname == O_SOUP && tick < 0 && count_of(there) > 0) new_obj = there & 0x00FFFFFFu;
-                } else if (hname == O_DISH && oname == O_SOUP && tick >= 0 && tick >= (int32_t)s_times[recipe_of(there)]) {
-                    new_held = there;
-                    new_obj = kItemNone;
-                    reward += (int32_t)p.soup_pickup_rew;
-                } else if (hname == O_ONION || hname == O_TOMATO) {
-                    uint32_t soup = oname == O_NONE ? (O_SOUP | kItemNone) : there;
-                    if (!((int8_t)(soup >> 24) >= 0 || count_of(soup) == kMaxIngredients)) {
-                        soup += hname == O_ONION ? 0x100u : 0x10000u;
-                        new_held = kItemNone;
-                        reward += (int32_t)p.placement_rew;
-                    }
-                    new_obj = soup;
-                }
-            }
-            obj[tgt] = new_obj;
-        } else if (terr == T_ONION_SRC) {
-            if (hname == O_NONE) new_held = O_ONION | kItemNone;
-        } else if (terr == T_TOMATO_SRC) {
-            if (hname == O_NONE) new_held = O_TOMATO | kItemNone;
-        } else if (terr == T_DISH_SRC) {
-            if (hname == O_NONE) new_held = O_DISH | kItemNone;
-        } else if (terr == T_SERVING) {
-            if (hname == O_SOUP) {
-                reward += (int32_t)s_values[recipe_of(held)];
-                new_held = kItemNone;
-            }
-        }
-        pl[2 * q + 1] = new_held;
+        const bool touches = terr == T_COUNTER || terr == T_POT;
+        uint32_t there = touches ? obj[tgt] : kItemNone;
+        const uint32_t before = there;
+        pl[2 * q + 1] = interact(p, s_times, s_values, terr, pl[2 * q + 1], there, reward);
+        if (touches && there != before) obj[tgt] = there;
     }
 
     // movement proposals (sim.cpp:363-379)
@@ -293,7 +348,27 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
     return reward;
 }
 
-template <bool kInit>
+// Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
+// for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
+#ifdef MRL_DIAG
+#define STAMP(k)                                                                                               \
+    do {                                                                                                       \
+        if (p.stamps && lane == 0)                                                                             \
+            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#define STAMP_REALTIME(k)                                                                                      \
+    do {                                                                                                       \
+        if (p.stamps && lane == 0)                                                                             \
+            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define ABLATED(bit) (p.ablate & (bit))
+#else
+#define STAMP(k) ((void)0)
+#define STAMP_REALTIME(k) ((void)0)
+#define ABLATED(bit) false
+#endif
+
+template <bool kInit, int kP>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -302,6 +377,8 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // wave-uniform values are forced into SGPRs so the address math around them is scalar
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
+    STAMP(0);
+    STAMP_REALTIME(13);
     // the constant block and the group's state slab are fetched together: one HBM/L2 latency
     const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
@@ -328,17 +405,43 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     uint4 *s_tail = reinterpret_cast<uint4 *>(wbase + p.off_tail);         // [wpw][C]
     uint8_t *s_tile = wbase + p.off_tile;
 
-    const uint32_t P = p.P, C = p.C, N = p.num_worlds;
+    const uint32_t P = kP > 0 ? (uint32_t)kP : p.P, C = p.C, N = p.num_worlds;
     const uint32_t ncells = nw * C, nplayers = nw * P;
 
+    int32_t t_loaded = 0;
     // ---------------- load: HBM slab -> LDS (straight copies) ----------------
+    // All global loads of the group are issued before the first one is consumed (explicitly
+    // batched: a plain copy loop waits for each load before issuing the next, which measured
+    // 2.1 us -- three to four dependent HBM/L2 latencies -- for a 1.2 KB slab).
     if (!kInit) {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
-        for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
         const uint2 *g_pl = p.players + (size_t)w0 * P;
-        for (uint32_t i = lane; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
+        constexpr int kBatch = 4;
+        uint32_t cell_reg[kBatch];
+        uint2 pl_reg = make_uint2(0, 0);
+        uint32_t act_reg[kBatch];
+        if (lane < nw) t_loaded = p.timestep[w0 + lane];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = lane + k * kWave;
+            cell_reg[k] = i < ncells ? g_obj[i] : 0u;
+        }
+        if (lane < nplayers) pl_reg = g_pl[lane];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) act_reg[k] = (lane < nw && (uint32_t)k < P) ? (uint32_t)p.actions[(size_t)k * N + w0 + lane] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = lane + k * kWave;
+            if (i < ncells) s_obj[i] = cell_reg[k];
+        }
+        for (uint32_t i = lane + kBatch * kWave; i < ncells; i += kWave) s_obj[i] = g_obj[i];
+        if (lane < nplayers) reinterpret_cast<uint2 *>(s_pl)[lane] = pl_reg;
+        for (uint32_t i = lane + kWave; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
         if (lane < nw) {
-            for (uint32_t q = 0; q < P; q++) {
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                if ((uint32_t)k < P) s_act[lane * P + k] = (uint8_t)(act_reg[k] <= A_INTERACT ? act_reg[k] : (uint32_t)A_STAY);
+            for (uint32_t q = kBatch; q < P; q++) {
                 const uint32_t a = (uint32_t)p.actions[(size_t)q * N + w0 + lane];
                 s_act[lane * P + q] = (uint8_t)(a <= A_INTERACT ? a : (uint32_t)A_STAY);  // outside the enum = outside the contract
             }
@@ -347,6 +450,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
     __syncthreads();
     if (nw == 0) return;
+    STAMP(1);
 
     // ---------------- step: lane = world ----------------
     if (lane < nw) {
@@ -356,9 +460,14 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         int32_t reward = 0, t = 0;
         bool reset_now = kInit;
         if (!kInit) {
-            if (!(p.ablate & 4)) reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
+            if (!ABLATED(4)) {
+                if constexpr (kP > 0)
+                    reward = transition_fixed<kP>(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
+                else
+                    reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
+            }
             // horizon (sim.cpp:485-489)
-            t = p.timestep[world] + 1;
+            t = t_loaded + 1;
             reset_now = (int64_t)t >= p.horizon;
         }
         // reset (sim.cpp:441-482)
@@ -375,6 +484,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         p.done[world] = kInit ? 0 : (int32_t)reset_now;
         s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;  // urgency channel (sim.cpp:79-83)
     }
+    STAMP(2);
     // cell -> player map for the encode
     for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
     wave_lds_sync();
@@ -390,6 +500,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
     }
 
+    STAMP(3);
     // ---------------- observe (sim.cpp:68-167, 642-645) ----------------
     // A row is [5P viewer-relative player channels][16 viewer-independent bytes].  The 16 bytes
     // (terrain one-hot, pot / soup / item channels incl. what the player standing there holds,
@@ -430,6 +541,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     }
     wave_lds_sync();
 
+    STAMP(4);
     // Rows are assembled kRowsPerPass at a time in an LDS tile and streamed out.  When a world
     // has no more rows than a tile, a pass covers whole worlds (p.wpp of them), so which
     // (world-in-pass, viewer, cell) a lane's rows are is the same in every pass and is worked
@@ -450,8 +562,16 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     }
     const uint32_t total_rows = nw * rows;
     uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    // p.steady: every pass of this wave starts at the same address mod 16 and covers whole
+    // worlds, so the tile is zero-filled once; a pass overwrites all 16-byte tails, sets the
+    // player bytes, streams the tile out and takes the player bytes back out.
+    if (p.steady) {
+        const uint32_t mis0 = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
+        const uint32_t nchunks = (mis0 + min(pass_rows, total_rows) * F + 15u) >> 4;
+        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    }
     uint32_t first_world = 0;  // of the current pass (aligned passes only)
-    for (uint32_t r0 = 0; r0 < ((p.ablate & 8) ? 0u : total_rows); r0 += pass_rows, first_world += p.wpp) {
+    for (uint32_t r0 = 0; r0 < (ABLATED(8) ? 0u : total_rows); r0 += pass_rows, first_world += p.wpp) {
         const uint32_t nrows = min(pass_rows, total_rows - r0);
         const uint32_t nbytes = nrows * F;
         uint8_t *g = gobs + (size_t)r0 * F;
@@ -460,54 +580,96 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 15u);
         uint8_t *tile = s_tile + mis;
 
-        const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
-        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        if (!p.steady) {
+            const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
+            for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        }
         wave_lds_sync();
 
+        // a lane's rows: indices, then all LDS reads together, then the stores
+        bool valid[kRowsPerLane], occupied[kRowsPerLane];
+        uint32_t cell[kRowsPerLane], pidx[kRowsPerLane], viewer[kRowsPerLane], who[kRowsPerLane], ori[kRowsPerLane];
+        uint4 t[kRowsPerLane];
 #pragma unroll
         for (uint32_t j = 0; j < kRowsPerLane; j++) {
             const uint32_t tr = lane * kRowsPerLane + j;
-            if (tr < nrows && !(p.ablate & 1)) {
-                uint32_t l, viewer, c;
-                if (p.wpp) {
-                    l = first_world + k_wl[j];
-                    viewer = k_viewer[j];
-                    c = k_c[j];
-                } else {
-                    const uint32_t gr = r0 + tr;
-                    l = __umulhi(gr, p.inv_rows);
-                    const uint32_t r = gr - __umul24(l, rows);
-                    viewer = __umulhi(r, p.inv_c);
-                    c = r - __umul24(viewer, C);
-                }
-                const uint32_t cell = __umul24(l, C) + c;
-                uint8_t *row = tile + __umul24(tr, F);
-                const uint4 t = s_tail[cell];
-                const uint32_t who = s_cur[cell];
-                // alignment class of row tr's tail; wave-uniform when F is even (tr has the parity of j)
-                const uint32_t cls = p.tail_even ? ((mis + j * F + shift) & 3u) : 1u;
-                lds_store_tail(row + shift, t, cls);
-                // the viewer-relative player channels: two bytes, only on occupied cells
-                if (who != 0xFF) {
-                    const uint32_t rel = who == viewer ? 0u : (who < viewer ? who + 1u : who);
-                    row[rel] = 1;
-                    row[P + 4 * rel + ((s_pl[(__umul24(l, P) + who) * 2] >> 8) & 0xFF)] = 1;
-                }
+            valid[j] = tr < nrows && !ABLATED(1);
+            uint32_t l, c;
+            if (p.wpp) {
+                l = first_world + k_wl[j];
+                viewer[j] = k_viewer[j];
+                c = k_c[j];
+            } else {
+                const uint32_t gr = r0 + tr;
+                l = __umulhi(gr, p.inv_rows);
+                const uint32_t r = gr - __umul24(l, rows);
+                viewer[j] = __umulhi(r, p.inv_c);
+                c = r - __umul24(viewer[j], C);
+            }
+            cell[j] = valid[j] ? __umul24(l, C) + c : 0u;
+            pidx[j] = valid[j] ? __umul24(l, P) : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            t[j] = s_tail[cell[j]];
+            who[j] = s_cur[cell[j]];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            occupied[j] = valid[j] && who[j] != 0xFF;
+            ori[j] = (s_pl[(pidx[j] + (occupied[j] ? who[j] : 0u)) * 2] >> 8) & 0xFF;
+        }
+        uint32_t mark_a[kRowsPerLane], mark_b[kRowsPerLane];  // tile offsets of the two player bytes
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            const uint32_t row = __umul24(lane * kRowsPerLane + j, F);
+            // alignment class of this row's tail; wave-uniform when F is even (the row index has the parity of j)
+            const uint32_t cls = p.tail_even ? ((mis + j * F + shift) & 3u) : 1u;
+            if (valid[j]) lds_store_tail(tile + row + shift, t[j], cls);
+            // the viewer-relative player channels: two bytes, only on occupied cells
+            const uint32_t rel = who[j] == viewer[j] ? 0u : (who[j] < viewer[j] ? who[j] + 1u : who[j]);
+            mark_a[j] = row + rel;
+            mark_b[j] = row + P + 4 * rel + ori[j];
+            if (occupied[j]) {
+                tile[mark_a[j]] = 1;
+                tile[mark_b[j]] = 1;
             }
         }
         wave_lds_sync();
 
-        // stream the tile out: unaligned head/tail bytes, 16-byte body
+        // stream the tile out: unaligned head/tail bytes, 16-byte body (LDS reads batched four deep)
         const uint32_t head = min((16u - mis) & 15u, nbytes);
         if (lane < head) g[lane] = tile[lane];
         const uint32_t body = (nbytes - head) >> 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
         uint4 *dst = reinterpret_cast<uint4 *>(g + head);
-        if (!(p.ablate & 2)) for (uint32_t k = lane; k < body; k += kWave) dst[k] = src[k];
+        if (!ABLATED(2)) {
+            for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+                const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+                const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
+                const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
+                if (ba) dst[ka] = va;
+                if (bb) dst[kb] = vb;
+                if (bc) dst[kc] = vc;
+                if (bd) dst[kd] = vd;
+            }
+        }
         const uint32_t done_bytes = head + (body << 4);
         if (lane < nbytes - done_bytes) g[done_bytes + lane] = tile[done_bytes + lane];
         wave_lds_sync();
+        if (p.steady) {
+#pragma unroll
+            for (uint32_t j = 0; j < kRowsPerLane; j++) {
+                if (occupied[j]) {
+                    tile[mark_a[j]] = 0;
+                    tile[mark_b[j]] = 0;
+                }
+            }
+        }
+        STAMP(5 + min(first_world / max(p.wpp, 1u), 8u));
     }
+    STAMP(15);
+    STAMP_REALTIME(14);
 }
 
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
@@ -536,10 +698,13 @@ struct OvercookedSim final : mrl_sim {
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
+        // two-player layouts (all five standard ones) take the register-resident transition
         if (init)
-            hipLaunchKernelGGL(mrl_overcooked_step<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        else if (a.P == 2)
+            hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
-            hipLaunchKernelGGL(mrl_overcooked_step<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL((mrl_overcooked_step<false, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         MRL_HIP(hipGetLastError());
     }
 
@@ -586,11 +751,17 @@ struct OvercookedSim final : mrl_sim {
         case MRL_OVERCOOKED_STATE_PLAYERS: *out = mrl::make_desc(params.players, MRL_UINT8, device, {N, P, 8}); return true;
         case MRL_OVERCOOKED_STATE_OBJECTS: *out = mrl::make_desc(params.cell_obj, MRL_UINT8, device, {N, C, 4}); return true;
         case MRL_OVERCOOKED_STATE_TIMESTEP: *out = mrl::make_desc(params.timestep, MRL_INT32, device, {N}); return true;
+#ifdef MRL_DIAG
+        case 14:
+            if (!params.stamps) return false;
+            *out = mrl::make_desc(params.stamps, MRL_UINT8, device, {(int64_t)grid * kWavesPerBlock * 16 * 8});
+            return true;
+#endif
         default: return false;
         }
     }
 
-    const char *kernel_name() const override { return "mrl_overcooked_step<false>"; }
+    const char *kernel_name() const override { return params.P == 2 ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
 
     uint64_t bytes_per_world_step() const override
     {
@@ -682,7 +853,11 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.num_pots = num_pots;
         a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
         a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;
+        a.steady = (a.wpp > 0 && ((uint64_t)a.wpp * a.block_bytes) % 16 == 0) ? 1u : 0u;
+#ifdef MRL_DIAG
         a.ablate = getenv("MRL_ABLATE") ? (uint32_t)atoi(getenv("MRL_ABLATE")) : 0u;
+        a.stamps = nullptr;
+#endif
         a.inv_p = P == 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)P) + 1u;  // x/1: umulhi(x, 2^32-1) == x-1 for x>0; handled in-kernel
         a.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)a.rows) + 1u;
         const uint32_t tile_bytes = (((uint32_t)kRowsPerPass * a.F + 15u) & ~15u) + 32u;
@@ -707,20 +882,25 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         } else {
             while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
         }
-        while (wpw > 1 && (layout(wpw) > 40960 || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
+        while (wpw > 1 && (layout(wpw) > 65536 || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
             wpw >>= 1;
         sim->lds_bytes = layout(wpw);
-        if (sim->lds_bytes > 65536)
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false>),
+        if (sim->lds_bytes > 65536) {
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
-        if (sim->lds_bytes > 65536)
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true>),
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+        }
         const uint32_t waves = (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
 
+#ifdef MRL_DIAG
+        if (getenv("MRL_STAMPS")) a.stamps = sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16);
+#endif
         uint32_t *d_consts = sim->arena.alloc<uint32_t>(kConstBytes / 4, false);
         MRL_HIP(hipMemcpy(d_consts, consts, kConstBytes, hipMemcpyHostToDevice));
         a.consts = d_consts;

@@ -1,0 +1,30 @@
+import os, sys, torch, numpy as np
+os.environ["MRL_STAMPS"] = "1"
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# needs the diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madrona_rl_envs_playground_amd import layouts
+from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
+n = 32768
+params = layouts.get_base_layout_params("cramped_room", 400)
+sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+pool = [torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(8)]
+for i in range(50):
+    sim.step_with_actions(pool[i % 8])
+torch.cuda.synchronize()
+st = sim._tensor(14).to_torch().cpu().numpy().view(np.uint64).reshape(-1, 16).astype(np.int64)
+st = st[st[:, 0] > 0]
+names = ["start", "loaded+sync", "transition", "curmap+store", "tails", "pass0", "pass1", "pass2", "pass3", "", "", "", "", "", "", "end"]
+cols = [k for k in range(16) if (st[:, k] > 0).all() and k not in (13, 14)]
+print("s_memtime deltas per wave (shader cycles; /2400 = us at 2.4 GHz), median [p10..p90] over", len(st), "waves")
+for a, b in zip(cols, cols[1:]):
+    d = st[:, b] - st[:, a]
+    print(f"{names[a]:>14s} -> {names[b]:14s} {np.median(d):8.0f}  [{np.percentile(d,10):7.0f} .. {np.percentile(d,90):7.0f}]  {np.median(d)/2400:5.2f} us")
+d = st[:, 15] - st[:, 0]
+print(f"wave lifetime median {np.median(d):.0f} cycles = {np.median(d)/2400:.2f} us, max {d.max()/2400:.2f} us")
+
+rs, re = st[:, 13] / 100.0, st[:, 14] / 100.0   # s_memrealtime: 100 MHz, common to the whole chip
+t0 = rs.min()
+print(f"wave starts (us after the first): p50 {np.median(rs - t0):.2f} p90 {np.percentile(rs - t0, 90):.2f} max {(rs - t0).max():.2f}")
+print(f"wave ends   (us after the first start): p10 {np.percentile(re - t0, 10):.2f} p50 {np.median(re - t0):.2f} max {(re - t0).max():.2f}")
