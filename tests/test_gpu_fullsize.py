@@ -1,0 +1,141 @@
+"""GPU, BASELINE.json's full sizes: size-independent properties instead of a
+lock-step oracle (which would take minutes of CPU at these sizes), plus a
+sampled lock-step against the oracle on a slice of the batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from madrona_rl_envs_playground_amd import layouts  # noqa: E402
+from madrona_rl_envs_playground_amd.simulators import (CartpoleSimulator, ExecMode, HanabiSimulator,  # noqa: E402
+                                                       OvercookedSimulator)
+
+
+def test_overcooked_32768_worlds_properties(hip_lib, oracle_lib):
+    """configs[1]: cramped_room, 32768 worlds, uniform random actions, seed 0."""
+    params = layouts.get_base_layout_params("cramped_room", 400)
+    n, P, H, W, F = 32768, 2, 4, 5, 26
+    C = H * W
+    sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+    obs = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    terrain = torch.tensor(params["terrain"], device="cuda")
+    onehot = torch.zeros(C, 6, dtype=torch.int8, device="cuda")
+    nz = terrain > 0
+    onehot[nz, (terrain[nz] - 1)] = 1
+    sample = 64  # worlds [0, sample) and the last `sample` worlds are also checked against the oracle
+    orc = oracle_lib.OvercookedOracle(params, 2 * sample, num_threads=4)
+    torch.manual_seed(0)
+    total_reward = 0
+    for t in range(420):  # crosses the horizon once
+        a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda")
+        sim.step_with_actions(a)
+        sel = torch.cat([a[:, :sample, 0], a[:, n - sample:, 0]], dim=1).cpu().numpy()
+        orc.step(sel)
+        if t % 30 == 0 or t >= 398:
+            o = obs
+            # terrain channels are the static layout, for every world and viewer
+            assert torch.equal(o[:, :, :, 10:16], onehot.expand(n, P, C, 6))
+            # every viewer sees itself exactly once and every other player exactly once, on walkable cells
+            assert (o[:, :, :, 0:2].sum(dim=2) == 1).all()
+            assert (o[:, :, :, 2:10].sum(dim=(2, 3)) == 2).all()          # one orientation bit per player
+            assert (o[:, :, :, 0:2].sum(dim=3) * (terrain != 0).to(torch.int8)).sum() == 0
+            # viewer 1's view is viewer 0's with the two player blocks swapped
+            assert torch.equal(o[:, 0, :, 0], o[:, 1, :, 1]) and torch.equal(o[:, 0, :, 2:6], o[:, 1, :, 6:10])
+            assert torch.equal(o[:, 0, :, 10:], o[:, 1, :, 10:])          # the 16-byte tails are viewer-independent
+            # urgency flag == (horizon - timestep < 40), uniform over the rows of a world
+            ts = sim.state_timestep_tensor().to_torch()
+            assert torch.equal(o[:, 0, 0, 25].to(torch.int32), ((400 - ts) < 40).to(torch.int32))
+            assert (ts == (t + 1) % 400).all()
+        rew = sim.reward_tensor().to_torch()
+        assert torch.equal(rew[0], rew[1]) and (rew >= 0).all()
+        total_reward += int(rew[0].sum())
+        done = sim.done_tensor().to_torch()
+        assert bool(done.all()) == (t == 399) and bool(done.any()) == (t == 399)
+        got = torch.cat([obs[:sample], obs[n - sample:]]).cpu().numpy().astype(np.uint8)
+        assert np.array_equal(got, orc.obs), f"sampled worlds differ from the oracle at step {t}"
+    assert total_reward > 0
+    sim.close()
+
+
+def test_overcooked_shard_invariance(hip_lib):
+    """Worlds are independent: one simulator of 2k worlds == two simulators of k worlds."""
+    params = layouts.get_base_layout_params("asymmetric_advantages", 70)
+    k = 4099
+    whole = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=2 * k, **params)
+    lo = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=k, **params)
+    hi = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=k, **params)
+    torch.manual_seed(4)
+    for _ in range(150):
+        a = torch.randint(0, 6, (2, 2 * k, 1), dtype=torch.int32, device="cuda")
+        whole.step_with_actions(a)
+        lo.step_with_actions(a[:, :k].contiguous())
+        hi.step_with_actions(a[:, k:].contiguous())
+        both = torch.cat([lo.observation_world_major_tensor().to_torch(), hi.observation_world_major_tensor().to_torch()])
+        assert torch.equal(both, whole.observation_world_major_tensor().to_torch())
+        assert torch.equal(torch.cat([lo.reward_tensor().to_torch(), hi.reward_tensor().to_torch()], dim=1),
+                           whole.reward_tensor().to_torch())
+    for s in (whole, lo, hi):
+        s.close()
+
+
+def test_hanabi_65536_worlds_properties(hip_lib):
+    """configs[2]: full 2-player Hanabi, 65536 worlds, masked-random legal actions."""
+    n = 65536
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                          max_information_tokens=8, max_life_tokens=3)
+    obs, state = sim.observation_tensor().to_torch(), sim.agent_state_tensor().to_torch()
+    mask, active = sim.action_mask_tensor().to_torch(), sim.active_agent_tensor().to_torch()
+    act = sim.action_tensor().to_torch()
+    torch.manual_seed(0)
+    idx = torch.arange(n, device="cuda")
+    finished = 0
+    prev_active = active.clone()
+    for t in range(60):
+        act.copy_((torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True))
+        sim.step()
+        done = sim.done_tensor().to_torch()
+        finished += int(done.sum())
+        assert (active.sum(0) == 1).all()
+        assert ((active[0] != prev_active[0]) | (done == 1)).all()           # the mover alternates unless the game ended
+        assert (active[0][done == 1] == 1).all()
+        cur = active[1].long()                                                # index of the active agent
+        o, s = obs[cur, idx], state[cur, idx]
+        info = o[:, 192:200].sum(1)
+        ok = info <= 8                                                        # skip worlds in the token-overflow encoding
+        assert torch.equal(s[ok][:, :658], o[ok])                             # state prefix == obs
+        deck, life = o[:, 127:167].sum(1), o[:, 200:203].sum(1)
+        ranks = torch.arange(1, 6, device="cuda")
+        fireworks = (o[:, 167:192].view(n, 5, 5).long() * ranks).sum(dim=(1, 2))       # one-hot of the top rank per colour
+        discards = o[:, 203:253].sum(1)
+        hands = o[:, :125].sum(1) + s[:, 658:783].sum(1)
+        assert ((deck + fireworks + discards + hands)[ok] == 50).all()        # card conservation
+        assert (life[ok] >= 1).all()                                          # finished games were re-dealt
+        m = mask[cur, idx]
+        assert (m[ok][:, 5:10].sum(1) == s[ok][:, 658:783].sum(1)).all()      # one play move per card in hand
+        assert ((m[:, 10:].sum(1) > 0) == (info > 0))[ok].all()               # hints need a token
+        assert ((m[:, :5].sum(1) > 0) == (info < 8))[ok].all()                # discards need room for a token
+        rew = sim.reward_tensor().to_torch()
+        assert torch.equal(rew[0], rew[1])
+        prev_active = active.clone()
+    assert finished > n  # more than one finished game per world on average
+    assert int(sim.reset_count_tensor().to_torch().item()) == int(sim.done_tensor().to_torch().sum())
+    sim.close()
+
+
+def test_cartpole_one_million_worlds(hip_lib):
+    n = 1 << 20
+    sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
+    st = sim.observation_tensor().to_torch()
+    assert st.abs().max() <= 0.05
+    torch.manual_seed(0)
+    resets = 0
+    for _ in range(40):
+        sim.step_with_actions(torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda"))
+        done = sim.reset_tensor().to_torch()[:, 0]
+        resets += int(done.sum())
+        assert (st[done == 1].abs() <= 0.05).all()                            # re-seeded worlds
+        assert (st[:, 0].abs() <= 2.4 + 0.2).all() and torch.isfinite(st).all()
+        assert int(sim.reset_count_tensor().to_torch().item()) == int(done.sum())
+    assert resets > n  # random policy: ~20-step episodes
+    sim.close()
