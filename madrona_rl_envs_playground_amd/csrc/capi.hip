@@ -59,6 +59,10 @@ static int need(const mrl_sim *sim)
         set_error("null simulator handle");
         return MRL_ERR_INVALID;
     }
+    // launches go to the simulator's device whatever the caller's current device is
+    // (one process may hold simulators on several GPUs)
+    int current = -1;
+    if (hipGetDevice(&current) == hipSuccess && current != sim->device) (void)hipSetDevice(sim->device);
     return MRL_OK;
 }
 

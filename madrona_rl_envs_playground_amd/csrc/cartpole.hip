@@ -15,6 +15,7 @@
 //   mrl_cartpole_reset: exclusive prefix over the counts, re-seed finished worlds
 // HBM traffic per world-step: action 4 + state r/w 32 + reward 4 + done 4 = 44 B.
 #include "common.hpp"
+#include "episode_scan.hpp"
 
 namespace {
 
@@ -82,14 +83,16 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint
     return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
 }
 
-__global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, const int32_t *__restrict__ action,
+// Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), chunk a
+// multiple of kBlock, and walks it kBlock worlds at a time.
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
                                                             float4 *__restrict__ state, float *__restrict__ reward,
                                                             int32_t *__restrict__ done, uint32_t *__restrict__ block_counts)
 {
     __shared__ uint32_t s_wave[kBlock / 64];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    bool over = false;
-    if (i < n) {
+    const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
+    uint32_t finished = 0;
+    for (uint32_t i = first + threadIdx.x; i < last; i += kBlock) {
         const float4 s = state[i];
         float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
         // sim.cpp:70-83; expression types as written there
@@ -105,17 +108,23 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, const in
         theta = theta + TAU * theta_dot;
         theta_dot = theta_dot + TAU * thetaacc;
         // sim.cpp:88-91
-        over = x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
+        const bool over = x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
         state[i] = make_float4(x, x_dot, theta, theta_dot);
         reward[i] = 1.f;
         done[i] = over ? 1 : 0;
+        finished += over ? 1u : 0u;
     }
-    uint32_t total;
-    (void)block_rank(over, s_wave, total);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) total += s_wave[w];
+        block_counts[blockIdx.x] = total;
+    }
 }
 
-__global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, const int32_t *__restrict__ done,
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_t chunk, const int32_t *__restrict__ done,
                                                              float4 *__restrict__ state,
                                                              const uint32_t *__restrict__ block_counts,
                                                              const uint32_t *__restrict__ episode_base,
@@ -123,25 +132,25 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, const i
                                                              uint32_t *__restrict__ reset_count)
 {
     __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_part[kBlock / 64];
-    // exclusive prefix of the counts of the workgroups before this one
-    uint32_t mine = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) mine += block_counts[b];
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    uint32_t prefix = 0;
-    for (uint32_t w = 0; w < kBlock / 64; w++) prefix += s_part[w];
-
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool over = i < n && done[i] != 0;
-    uint32_t total;
-    const uint32_t rank = block_rank(over, s_wave, total);
+    __shared__ uint32_t s_red[2 * kBlock / 64];
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
+    uint32_t grand_total = 0;
+    uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
     const uint32_t base = *episode_base;
-    if (over) state[i] = fresh_state(base + prefix + rank);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        *reset_count = prefix + total;
-        *next_counter = base + prefix + total;
+    const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
+    for (uint32_t i0 = first; i0 < last; i0 += kBlock) {  // uniform trip count
+        const uint32_t i = i0 + threadIdx.x;
+        const bool over = i < last && done[i] != 0;
+        uint32_t total;
+        const uint32_t rank = block_rank(over, s_wave, total);
+        if (over) state[i] = fresh_state(base + running + rank);
+        running += total;
+        __syncthreads();  // s_wave is reused by the next round
+    }
+    if (last_block && threadIdx.x == 0) {
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
     }
 }
 
@@ -160,13 +169,14 @@ struct CartpoleSim final : mrl_sim {
     float4 *state = nullptr;
     float *reward = nullptr;
     uint32_t *block_counts = nullptr;
+    uint32_t chunk = 0;  // worlds per workgroup
     uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
     uint32_t *reset_count = nullptr;
     uint32_t parity = 0;
 
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds,
+        hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk,
                            actions ? actions : action, state, reward, done, block_counts);
         MRL_HIP(hipGetLastError());
     }
@@ -174,7 +184,7 @@ struct CartpoleSim final : mrl_sim {
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
-        hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, done, state,
+        hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, state,
                            block_counts, base, counter + (parity ^ 1u), reset_count);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -188,8 +198,8 @@ struct CartpoleSim final : mrl_sim {
 
     void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl_cartpole_init, dim3(grid), dim3(kBlock), 0, stream, num_worlds, world_offset, state,
-                           world_id);
+        hipLaunchKernelGGL(mrl_cartpole_init, dim3((num_worlds + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, num_worlds,
+                           world_offset, state, world_id);
         MRL_HIP(hipGetLastError());
         MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
         MRL_HIP(hipMemsetAsync(reward, 0, sizeof(float) * num_worlds, stream));
@@ -228,7 +238,12 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->game = MRL_GAME_CARTPOLE;
         sim->device = gpu_id;
         sim->num_worlds = num_worlds;
-        sim->grid = (num_worlds + kBlock - 1) / kBlock;
+        {
+            const uint32_t groups = (num_worlds + kBlock - 1) / kBlock;
+            const uint32_t blocks = groups < mrl::kMaxScanBlocks ? groups : mrl::kMaxScanBlocks;
+            sim->chunk = ((groups + blocks - 1) / blocks) * kBlock;
+            sim->grid = (num_worlds + sim->chunk - 1) / sim->chunk;
+        }
         sim->action = sim->arena.alloc<int32_t>(num_worlds);
         sim->done = sim->arena.alloc<int32_t>(num_worlds);
         sim->world_id = sim->arena.alloc<int32_t>(num_worlds);

@@ -26,6 +26,7 @@
 //   mrl_hanabi_step : action + encode + score/done + per-workgroup done counts
 //   mrl_hanabi_reset: prefix over the counts, re-deal finished worlds, encode both agents
 #include "common.hpp"
+#include "episode_scan.hpp"
 
 namespace {
 
@@ -71,6 +72,7 @@ struct HanabiParams {
     int32_t *done;       // N
     const int32_t *actions;  // 2 x N
     uint32_t *block_counts;
+    uint32_t chunk;  // worlds per workgroup (multiple of kWorldsPerBlock)
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -440,56 +442,63 @@ __device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLd
         p.records[(size_t)(w0 + r) * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
 }
 
+// Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), p.chunk a
+// multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
     const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t w0 = blockIdx.x * kWorldsPerBlock + wib * kWorldsPerWave;
-    const uint32_t nw = w0 < p.num_worlds ? min((uint32_t)kWorldsPerWave, p.num_worlds - w0) : 0u;
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
+    const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
+    uint32_t finished = 0;
 
-    load_records(p, l, w0, nw, lane);
-    wave_lds_sync();
+    for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {
+        const uint32_t w0 = sub + wib * kWorldsPerWave;
+        const uint32_t nw = w0 < chunk_end ? min((uint32_t)kWorldsPerWave, chunk_end - w0) : 0u;
+        load_records(p, l, w0, nw, lane);
+        wave_lds_sync();
 
-    bool over = false;
-    if (lane < nw) {
-        uint8_t *rec = l.rec + lane * kRecStride;
-        uint32_t *enc = l.enc + lane * 2 * kEncWords;
-        const uint32_t world = w0 + lane;
-        const uint32_t actor = rec[R_CUR] & 1u;
-        apply_action(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
-        const uint32_t next = rec[R_CUR] & 1u;
-        // observationSystem (:794-810): only the player to move is refreshed
-        encode_agent(p, rec, enc, next);
-        p.active[(size_t)next * N + world] = 1;
-        p.active[(size_t)(next ^ 1u) * N + world] = 0;
-        // checkDone (:812-850)
-        const int32_t old_score = (int8_t)rec[R_SCORE];
-        int32_t score = 0;
-        if (rec[R_LIFE] > 0)
-            for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
-        rec[R_SCORE] = (uint8_t)score;
-        rec[R_NEWREW] = (uint8_t)(score - old_score);
-        const float rew = (float)(int8_t)(score - old_score);
-        p.reward[world] = rew;
-        p.reward[(size_t)N + world] = rew;
-        over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * p.ranks || (int8_t)rec[R_TURNS] <= 0;
-        p.done[world] = over ? 1 : 0;
+        bool over = false;
+        if (lane < nw) {
+            uint8_t *rec = l.rec + lane * kRecStride;
+            uint32_t *enc = l.enc + lane * 2 * kEncWords;
+            const uint32_t world = w0 + lane;
+            const uint32_t actor = rec[R_CUR] & 1u;
+            apply_action(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
+            const uint32_t next = rec[R_CUR] & 1u;
+            // observationSystem (:794-810): only the player to move is refreshed
+            encode_agent(p, rec, enc, next);
+            p.active[(size_t)next * N + world] = 1;
+            p.active[(size_t)(next ^ 1u) * N + world] = 0;
+            // checkDone (:812-850)
+            const int32_t old_score = (int8_t)rec[R_SCORE];
+            int32_t score = 0;
+            if (rec[R_LIFE] > 0)
+                for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
+            rec[R_SCORE] = (uint8_t)score;
+            rec[R_NEWREW] = (uint8_t)(score - old_score);
+            const float rew = (float)(int8_t)(score - old_score);
+            p.reward[world] = rew;
+            p.reward[(size_t)N + world] = rew;
+            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * p.ranks || (int8_t)rec[R_TURNS] <= 0;
+            p.done[world] = over ? 1 : 0;
+        }
+        finished += (uint32_t)__popcll(__ballot(over));
+        wave_lds_sync();
+
+        // phase B: bits -> bytes for every world's player to move
+        for (uint32_t task = lane; task < nw * kChunksPerAgent; task += kWave) {
+            const uint32_t r = task / kChunksPerAgent, chunk = task - r * kChunksPerAgent;
+            const uint32_t agent = l.rec[r * kRecStride + R_CUR] & 1u;
+            expand_chunk(p, l.enc + r * 2 * kEncWords, agent, w0 + r, chunk);
+        }
+        for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
+        wave_lds_sync();
     }
-    const unsigned long long votes = __ballot(over);
-    wave_lds_sync();
 
-    // phase B: bits -> bytes for every world's player to move
-    for (uint32_t task = lane; task < nw * kChunksPerAgent; task += kWave) {
-        const uint32_t r = task / kChunksPerAgent, chunk = task - r * kChunksPerAgent;
-        const uint32_t agent = l.rec[r * kRecStride + R_CUR] & 1u;
-        expand_chunk(p, l.enc + r * 2 * kEncWords, agent, w0 + r, chunk);
-    }
-    for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
-
-    if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
+    if (lane == 0) s_counts[wib] = finished;
     __syncthreads();
     if (threadIdx.x == 0) p.block_counts[blockIdx.x] = s_counts[0] + s_counts[1] + s_counts[2] + s_counts[3];
 }
@@ -504,65 +513,70 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
-    __shared__ uint32_t s_part[kWavesPerBlock];
+    __shared__ uint32_t s_part[2 * kWavesPerBlock];
     const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const uint32_t w0 = blockIdx.x * kWorldsPerBlock + wib * kWorldsPerWave;
-    const uint32_t nw = w0 < p.num_worlds ? min((uint32_t)kWorldsPerWave, p.num_worlds - w0) : 0u;
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
     const bool last_block = blockIdx.x == gridDim.x - 1;
+    const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
 
-    uint32_t prefix = 0;
+    uint32_t running = 0, grand_total = 0;  // finished worlds before the current sub-block
     if (!kAll) {
         if (p.block_counts[blockIdx.x] == 0 && !last_block) return;  // uniform for the workgroup
-        uint32_t mine = 0;
-        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) mine += p.block_counts[b];
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-        if (lane == 0) s_part[wib] = mine;
-        __syncthreads();
-        prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    }
-
-    const bool over = lane < nw && (kAll || p.done[w0 + lane] != 0);
-    const unsigned long long votes = __ballot(over);
-    if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < kWavesPerBlock; w++) {
-        before += w < wib ? s_counts[w] : 0u;
-        total += s_counts[w];
+        running = mrl::scan_prefix(p.block_counts, gridDim.x, blockIdx.x, s_part, last_block, &grand_total);
     }
     const uint32_t base = kAll ? episode_base_value : *episode_base;
     if (!kAll && last_block && threadIdx.x == 0) {
-        *reset_count = prefix + total;
-        *next_counter = base + prefix + total;
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
     }
-    if (votes == 0ull) return;
 
-    if (over) {
-        uint8_t *rec = l.rec + lane * kRecStride;
-        const uint32_t rank = kAll ? (w0 + lane) : prefix + before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
-        deal_new_game(p, rec, base + rank);
-        encode_agent(p, rec, l.enc + lane * 2 * kEncWords, 0);
-        encode_agent(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
-        p.active[w0 + lane] = 1;
-        p.active[(size_t)N + w0 + lane] = 0;
-        if (kAll) {
-            p.reward[w0 + lane] = 0.f;
-            p.reward[(size_t)N + w0 + lane] = 0.f;
-            p.done[w0 + lane] = 0;
+    for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {  // uniform trip count
+        const uint32_t w0 = sub + wib * kWorldsPerWave;
+        const uint32_t nw = w0 < chunk_end ? min((uint32_t)kWorldsPerWave, chunk_end - w0) : 0u;
+        const bool over = lane < nw && (kAll || p.done[w0 + lane] != 0);
+        const unsigned long long votes = __ballot(over);
+        uint32_t before = 0;
+        if (!kAll) {
+            if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
+            __syncthreads();
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < kWavesPerBlock; w++) {
+                before += w < wib ? s_counts[w] : 0u;
+                total += s_counts[w];
+            }
+            __syncthreads();
+            before += running;
+            running += total;
         }
-    }
-    wave_lds_sync();
-    unsigned long long todo = votes;
-    while (todo) {
-        const uint32_t r = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        for (uint32_t task = lane; task < 2 * kChunksPerAgent; task += kWave) {
-            const uint32_t agent = task / kChunksPerAgent, chunk = task - agent * kChunksPerAgent;
-            expand_chunk(p, l.enc + (r * 2 + agent) * kEncWords, agent, w0 + r, chunk);
+        if (votes == 0ull) continue;
+
+        if (over) {
+            uint8_t *rec = l.rec + lane * kRecStride;
+            const uint32_t rank = kAll ? (w0 + lane) : before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+            deal_new_game(p, rec, base + rank);
+            encode_agent(p, rec, l.enc + lane * 2 * kEncWords, 0);
+            encode_agent(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
+            p.active[w0 + lane] = 1;
+            p.active[(size_t)N + w0 + lane] = 0;
+            if (kAll) {
+                p.reward[w0 + lane] = 0.f;
+                p.reward[(size_t)N + w0 + lane] = 0.f;
+                p.done[w0 + lane] = 0;
+            }
         }
-        store_record(p, l, w0, r, lane);
+        wave_lds_sync();
+        unsigned long long todo = votes;
+        while (todo) {
+            const uint32_t r = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            for (uint32_t task = lane; task < 2 * kChunksPerAgent; task += kWave) {
+                const uint32_t agent = task / kChunksPerAgent, chunk = task - agent * kChunksPerAgent;
+                expand_chunk(p, l.enc + (r * 2 + agent) * kEncWords, agent, w0 + r, chunk);
+            }
+            store_record(p, l, w0, r, lane);
+        }
+        wave_lds_sync();
     }
 }
 
@@ -676,7 +690,12 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->game = MRL_GAME_HANABI;
         sim->device = gpu_id;
         sim->num_worlds = num_worlds;
-        sim->grid = (num_worlds + kWorldsPerBlock - 1) / kWorldsPerBlock;
+        {
+            const uint32_t groups = (num_worlds + kWorldsPerBlock - 1) / kWorldsPerBlock;
+            const uint32_t blocks = groups < mrl::kMaxScanBlocks ? groups : mrl::kMaxScanBlocks;
+            sim->params.chunk = ((groups + blocks - 1) / blocks) * kWorldsPerBlock;
+            sim->grid = (num_worlds + sim->params.chunk - 1) / sim->params.chunk;
+        }
         HanabiParams &a = sim->params;
         const uint32_t K = cfg->colors, R = cfg->ranks, N = num_worlds;
         a.num_worlds = N;
