@@ -74,6 +74,8 @@ struct StepParams {
     // x / d == umulhi(x, floor(2^32/d)+1) while x*d < 2^32 (checked on the host)
     uint32_t inv_c, inv_p, inv_rows;
     uint32_t placement_rew, soup_pickup_rew;
+    uint32_t times_w[4], values_w[4];  // the 16-entry recipe tables, 4 bytes per word (scalar registers)
+    uint32_t pots_w;       // cells of the first four pots, one byte each
     uint32_t wpw;          // worlds per wave
     uint32_t wpp;          // whole worlds per observation pass (0: a world spans several passes)
     uint32_t num_pots;
@@ -163,6 +165,37 @@ __device__ __forceinline__ void lds_store_tail(uint8_t *ptr, const uint4 &t, uin
     }
 }
 
+// 16-byte store of observation bytes.  The observation slab (34 MB per launch at 32768
+// worlds) is written once and not read again by this kernel, and it is larger than the L2s:
+// with plain stores the dirty lines pile up in L2 and are written back in the end-of-kernel
+// release, which the next launch waits for.  sc1 (write-through, line not kept) streams them
+// out while the waves are still working.  Measured on MI355X, us per launch at 32768 worlds:
+// plain 14.05, nt 13.44, sc1 11.78, sc0 sc1 11.79.  MRL_STORE_POLICY (0 plain, 1 nt, 2 sc1,
+// 3 sc0 sc1) exists to re-measure.
+#ifndef MRL_STORE_POLICY
+#define MRL_STORE_POLICY 2
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(uint4 *dst, const uint4 &v)
+{
+#if MRL_STORE_POLICY == 0
+    *dst = v;
+#else
+    u32x4 r;
+    r.x = v.x;
+    r.y = v.y;
+    r.z = v.z;
+    r.w = v.w;
+#if MRL_STORE_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(r) : "memory");
+#elif MRL_STORE_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(r) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(r) : "memory");
+#endif
+#endif
+}
+
 __device__ __forceinline__ int32_t step_of(uint32_t dir, uint32_t width)
 {
     // sim.cpp:185-197
@@ -178,17 +211,24 @@ __device__ __forceinline__ uint32_t count_of(uint32_t item) { return (((item >> 
 
 // The counter/pot/source/serving interaction of one player (sim.cpp:208-358), shared by the
 // generic and the register-resident transition.  `there` is the object on the faced cell
-// (only read for counters and pots); returns the player's new held item.
-__device__ __forceinline__ uint32_t interact(const StepParams &p, const uint8_t *s_times, const uint8_t *s_values,
-                                             uint32_t terr, uint32_t held, uint32_t &there, int32_t &reward)
+// (only meaningful for counters and pots), `need` its cooking time and `value` the delivery
+// value of the held soup; returns the player's new held item.
+// 16-entry byte table held in four scalar registers: a few selects instead of an LDS round trip
+__device__ __forceinline__ uint32_t lookup16(const uint32_t (&w)[4], uint32_t idx)
+{
+    const uint32_t hi = idx >> 2;
+    const uint32_t word = hi == 0 ? w[0] : hi == 1 ? w[1] : hi == 2 ? w[2] : w[3];
+    return (word >> ((idx & 3u) * 8u)) & 0xFFu;
+}
+
+__device__ __forceinline__ uint32_t interact(const StepParams &p, int32_t need, int32_t value, uint32_t terr, uint32_t held,
+                                             uint32_t &there, int32_t &reward)
 {
     // Straight-line selects instead of the if/else ladder of sim.cpp:229-253,299-335: lanes of
     // one wave are different worlds taking different branches, so a ladder costs the sum of
     // all its arms anyway; this form is shorter than that sum.
     const uint32_t hname = held & 0xFF, oname = there & 0xFF;
     const int32_t tick = (int8_t)(there >> 24);
-    const int32_t need = (int32_t)s_times[recipe_of(there)];
-    const int32_t value = (int32_t)s_values[recipe_of(held)];
     const bool counter = terr == T_COUNTER, pot = terr == T_POT;
     const bool empty_handed = hname == O_NONE, nothing_there = oname == O_NONE, soup_there = oname == O_SOUP;
     // counter: put down / pick up
@@ -226,8 +266,7 @@ __device__ __forceinline__ uint32_t interact(const StepParams &p, const uint8_t 
 // order.  Same semantics as `transition` below.
 template <int kP>
 __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
-                                                    const uint8_t *s_values, const uint8_t *s_pots, uint32_t *obj,
-                                                    uint32_t *pl, const uint8_t *act)
+                                                    const uint8_t *s_pots, uint32_t *obj, uint32_t *pl, const uint8_t *act)
 {
     uint32_t posori[kP], held[kP], a[kP], tgt[kP], terr[kP], ahead[kP];
 #pragma unroll
@@ -243,15 +282,19 @@ __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const u
         terr[q] = s_terrain[tgt[q]];
         ahead[q] = s_terrain[pos + (uint32_t)step_of(a[q], p.W)];  // STAY / INTERACT: own cell (AIR)
     }
+    // (Reading every touched object up front and forwarding later writers in registers was
+    // tried: no faster -- this phase is bound by instruction issue on 8 active lanes, not by
+    // the LDS round trips.)
     int32_t reward = 0;
 #pragma unroll
     for (int q = 0; q < kP; q++) {
         if (a[q] != A_INTERACT) continue;
         const bool touches = terr[q] == T_COUNTER || terr[q] == T_POT;
         uint32_t there = touches ? obj[tgt[q]] : kItemNone;
-        const uint32_t before = there;
-        held[q] = interact(p, s_times, s_values, terr[q], held[q], there, reward);
-        if (touches && there != before) obj[tgt[q]] = there;
+        const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(there));
+        const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held[q]));
+        held[q] = interact(p, need, value, terr[q], held[q], there, reward);
+        if (touches) obj[tgt[q]] = there;
     }
     uint32_t pos[kP], prop[kP], pori[kP];
 #pragma unroll
@@ -275,13 +318,13 @@ __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const u
         pl[2 * q] = (blocked ? pos[q] : prop[q]) | (pori[q] << 8);
         pl[2 * q + 1] = held[q];
     }
+    // pots (sim.cpp:430-438), after the interactions: a pot started this step is already at 1
     for (uint32_t k = 0; k < p.num_pots; k++) {
-        const uint32_t c = s_pots[k];
+        const uint32_t c = k < 4 ? (p.pots_w >> (8 * k)) & 0xFFu : (uint32_t)s_pots[k];
         const uint32_t o = obj[c];
-        if ((o & 0xFF) == O_SOUP) {
-            const int32_t tick = (int8_t)(o >> 24);
-            if (tick >= 0 && tick < (int32_t)s_times[recipe_of(o)]) obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
-        }
+        const int32_t tick = (int8_t)(o >> 24);
+        if ((o & 0xFF) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o)))
+            obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
     }
     return reward;
 }
@@ -303,7 +346,9 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
         const bool touches = terr == T_COUNTER || terr == T_POT;
         uint32_t there = touches ? obj[tgt] : kItemNone;
         const uint32_t before = there;
-        pl[2 * q + 1] = interact(p, s_times, s_values, terr, pl[2 * q + 1], there, reward);
+        const uint32_t in_hand = pl[2 * q + 1];
+        pl[2 * q + 1] = interact(p, (int32_t)s_times[recipe_of(there)], (int32_t)s_values[recipe_of(in_hand)], terr, in_hand, there,
+                                 reward);
         if (touches && there != before) obj[tgt] = there;
     }
 
@@ -453,6 +498,8 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     STAMP(1);
 
     // ---------------- step: lane = world ----------------
+    // (Letting one wave step all worlds of the workgroup, with the other waves waiting, was
+    // tried and is no faster: this phase is ~2 us of dependent per-world logic either way.)
     if (lane < nw) {
         uint32_t *obj = s_obj + lane * C;
         uint32_t *pl = s_pl + lane * 2 * P;
@@ -462,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         if (!kInit) {
             if (!ABLATED(4)) {
                 if constexpr (kP > 0)
-                    reward = transition_fixed<kP>(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
+                    reward = transition_fixed<kP>(p, s_terrain, s_times, s_pots, obj, pl, s_act + lane * P);
                 else
                     reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
             }
@@ -513,7 +560,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint32_t who = s_cur[i];
         const uint32_t urgent = s_flags[l];
         const uint32_t h = who != 0xFF ? s_pl[(__umul24(l, P) + who) * 2 + 1] : kItemNone;
-        const int32_t need = (int32_t)s_times[recipe_of(o)];
+        const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(o));
         const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, tom = (o >> 16) & 0xFF;
         const int32_t tick = (int8_t)(o >> 24);
         const uint32_t hname = h & 0xFF;
@@ -648,10 +695,10 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
                 const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
                 const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
                 const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
-                if (ba) dst[ka] = va;
-                if (bb) dst[kb] = vb;
-                if (bc) dst[kc] = vc;
-                if (bd) dst[kd] = vd;
+                if (ba) stream_store(dst + ka, va);
+                if (bb) stream_store(dst + kb, vb);
+                if (bc) stream_store(dst + kc, vc);
+                if (bd) stream_store(dst + kd, vd);
             }
         }
         const uint32_t done_bytes = head + (body << 4);
@@ -851,6 +898,9 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.soup_pickup_rew = (uint8_t)cfg->soup_pickup_rew;
         a.horizon = cfg->horizon;
         a.num_pots = num_pots;
+        memcpy(a.times_w, consts + kConstTimes, 16);
+        memcpy(a.values_w, consts + kConstValues, 16);
+        memcpy(&a.pots_w, consts + kConstPots, 4);
         a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
         a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;
         a.steady = (a.wpp > 0 && ((uint64_t)a.wpp * a.block_bytes) % 16 == 0) ? 1u : 0u;
