@@ -69,6 +69,7 @@ constexpr uint32_t kConstBytes = 608;
 struct StepParams {
     uint32_t num_worlds;
     uint32_t P, C, W, F;
+    uint64_t deltas;       // move deltas as signed bytes, see step_of
     uint32_t rows;         // P*C
     uint32_t block_bytes;  // P*C*F
     // x / d == umulhi(x, floor(2^32/d)+1) while x*d < 2^32 (checked on the host)
@@ -196,10 +197,13 @@ __device__ __forceinline__ void stream_store(uint4 *dst, const uint4 &v)
 #endif
 }
 
-__device__ __forceinline__ int32_t step_of(uint32_t dir, uint32_t width)
+// Cell-index delta of a move (sim.cpp:185-197): NORTH -W, SOUTH +W, EAST +1, WEST -1, STAY and
+// INTERACT 0.  `deltas` packs them as signed bytes (|W| <= 85 since H >= 3 and H*W <= 255),
+// byte k = delta of direction k; one 64-bit shift instead of a compare ladder -- hipcc lowers
+// such ladders to exec-masked branch trees, which cost ~20 instructions each on divergent lanes.
+__device__ __forceinline__ int32_t step_of(uint32_t dir, uint64_t deltas)
 {
-    // sim.cpp:185-197
-    return dir == A_NORTH ? -(int32_t)width : dir == A_SOUTH ? (int32_t)width : dir == A_EAST ? 1 : dir == A_WEST ? -1 : 0;
+    return (int32_t)(int8_t)(deltas >> (8u * dir));
 }
 
 __device__ __forceinline__ uint32_t recipe_of(uint32_t item)
@@ -213,12 +217,13 @@ __device__ __forceinline__ uint32_t count_of(uint32_t item) { return (((item >> 
 // generic and the register-resident transition.  `there` is the object on the faced cell
 // (only meaningful for counters and pots), `need` its cooking time and `value` the delivery
 // value of the held soup; returns the player's new held item.
-// 16-entry byte table held in four scalar registers: a few selects instead of an LDS round trip
+// 16-entry byte table held in four scalar registers: one select and a 64-bit shift instead of
+// an LDS round trip (and no compare ladder, see step_of)
 __device__ __forceinline__ uint32_t lookup16(const uint32_t (&w)[4], uint32_t idx)
 {
-    const uint32_t hi = idx >> 2;
-    const uint32_t word = hi == 0 ? w[0] : hi == 1 ? w[1] : hi == 2 ? w[2] : w[3];
-    return (word >> ((idx & 3u) * 8u)) & 0xFFu;
+    const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    const uint64_t half = (idx & 8u) ? hi : lo;
+    return (uint32_t)(half >> ((idx & 7u) * 8u)) & 0xFFu;
 }
 
 __device__ __forceinline__ uint32_t interact(const StepParams &p, int32_t need, int32_t value, uint32_t terr, uint32_t held,
@@ -242,7 +247,8 @@ __device__ __forceinline__ uint32_t interact(const StepParams &p, int32_t need, 
     const bool add = ingredient & !(((int8_t)(soup >> 24) >= 0) | (count_of(soup) == kMaxIngredients));
     // sources and serving window
     const bool source = (terr == T_ONION_SRC) | (terr == T_TOMATO_SRC) | (terr == T_DISH_SRC);
-    const uint32_t fresh = (terr == T_ONION_SRC ? (uint32_t)O_ONION : terr == T_TOMATO_SRC ? (uint32_t)O_TOMATO : (uint32_t)O_DISH) | kItemNone;
+    // ONION_SRC(3) -> ONION(2), TOMATO_SRC(4) -> TOMATO(1), DISH_SRC(5) -> DISH(3), as a packed table
+    const uint32_t fresh = ((0x00030102u >> (((terr - T_ONION_SRC) & 3u) * 8u)) & 0xFFu) | kItemNone;
     const bool grab = source & empty_handed;
     const bool serve = (terr == T_SERVING) & (hname == O_SOUP);
 
@@ -278,9 +284,9 @@ __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const u
 #pragma unroll
     for (int q = 0; q < kP; q++) {
         const uint32_t pos = posori[q] & 0xFF, ori = posori[q] >> 8;
-        tgt[q] = pos + (uint32_t)step_of(ori, p.W);
+        tgt[q] = pos + (uint32_t)step_of(ori, p.deltas);
         terr[q] = s_terrain[tgt[q]];
-        ahead[q] = s_terrain[pos + (uint32_t)step_of(a[q], p.W)];  // STAY / INTERACT: own cell (AIR)
+        ahead[q] = s_terrain[pos + (uint32_t)step_of(a[q], p.deltas)];  // STAY / INTERACT: own cell (AIR)
     }
     // (Reading every touched object up front and forwarding later writers in registers was
     // tried: no faster -- this phase is bound by instruction issue on 8 active lanes, not by
@@ -305,7 +311,7 @@ __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const u
         pori[q] = ori;
         if (a[q] != A_INTERACT) {
             pori[q] = a[q] == A_STAY ? ori : a[q];
-            prop[q] = ahead[q] != T_AIR ? pos[q] : pos[q] + (uint32_t)step_of(a[q], p.W);
+            prop[q] = ahead[q] != T_AIR ? pos[q] : pos[q] + (uint32_t)step_of(a[q], p.deltas);
         }
     }
     bool blocked = false;
@@ -341,7 +347,7 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
     for (uint32_t q = 0; q < P; q++) {
         if (act[q] != A_INTERACT) continue;
         const uint32_t posori = pl[2 * q];
-        const uint32_t tgt = (posori & 0xFF) + (uint32_t)step_of((posori >> 8) & 0xFF, p.W);
+        const uint32_t tgt = (posori & 0xFF) + (uint32_t)step_of((posori >> 8) & 0xFF, p.deltas);
         const uint32_t terr = s_terrain[tgt];
         const bool touches = terr == T_COUNTER || terr == T_POT;
         uint32_t there = touches ? obj[tgt] : kItemNone;
@@ -358,7 +364,7 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
         const uint32_t pos = posori & 0xFF, ori = posori >> 8;
         uint32_t prop = pos, pori = ori;
         if (a != A_INTERACT) {
-            const uint32_t np = pos + (uint32_t)step_of(a, p.W);
+            const uint32_t np = pos + (uint32_t)step_of(a, p.deltas);
             pori = a == A_STAY ? ori : a;
             prop = s_terrain[np] != T_AIR ? pos : np;
         }
@@ -898,6 +904,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.soup_pickup_rew = (uint8_t)cfg->soup_pickup_rew;
         a.horizon = cfg->horizon;
         a.num_pots = num_pots;
+        a.deltas = (uint64_t)(uint8_t)(int8_t)(-W) | ((uint64_t)(uint8_t)(int8_t)W << 8) | (1ull << 16) | (0xFFull << 24);
         memcpy(a.times_w, consts + kConstTimes, 16);
         memcpy(a.values_w, consts + kConstValues, 16);
         memcpy(&a.pots_w, consts + kConstPots, 4);
