@@ -84,6 +84,7 @@ struct StepParams {
     uint32_t ablate;             // diagnostic build only: phase ablation mask
     unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps
 #endif
+    uint32_t whole;        // a group's whole observation slab fits one LDS tile: single-pass encode
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
     uint32_t off_pl, off_act, off_cur, off_flags, off_tail, off_tile;  // byte offsets inside a wave's LDS region
@@ -270,6 +271,39 @@ __device__ __forceinline__ uint32_t interact(const StepParams &p, int32_t need, 
 // that does not depend on an earlier write (player records, actions, terrain of the faced and
 // of the target cells) is issued up front, and only the faced cells' objects are touched in
 // order.  Same semantics as `transition` below.
+// The 16 viewer-independent bytes of a cell's observation rows, row[5P .. 5P+16): terrain
+// one-hot (6), idle pot onions/tomatoes, soup onions/tomatoes, remaining time, ready, dish,
+// onion, tomato, urgency (sim.cpp:79-120,151-164; terrain bytes :642-645).  `o` is the object on
+// the cell, `h` what the player standing there holds (kItemNone if nobody).  Straight-line selects.
+__device__ __forceinline__ uint4 cell_tail(const StepParams &p, uint32_t terr, uint32_t o, uint32_t h, uint32_t urgent)
+{
+    const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(o));
+    const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, tom = (o >> 16) & 0xFF;
+    const int32_t tick = (int8_t)(o >> 24);
+    const uint32_t hname = h & 0xFF;
+    const bool is_soup = oname == O_SOUP, in_pot = terr == T_POT;
+    const bool idle = is_soup & in_pot & (tick < 0);
+    const bool hot = is_soup & in_pot & (tick >= 0);
+    const bool plated = is_soup & !in_pot;
+    const bool hsoup = hname == O_SOUP;  // a soup in hand overrides the cell's soup channels
+    const uint32_t idle_on = idle ? on : 0u, idle_tom = idle ? tom : 0u;
+    const uint32_t soup_on = hsoup ? (h >> 8) & 0xFF : ((hot | plated) ? on : 0u);
+    const uint32_t soup_tom = hsoup ? (h >> 16) & 0xFF : ((hot | plated) ? tom : 0u);
+    const uint32_t remaining = (hot & !hsoup) ? (uint32_t)(need - tick) & 0xFF : 0u;
+    const uint32_t ready = (hsoup | plated | (hot & (tick >= need))) ? 1u : 0u;
+    const uint32_t dish = ((oname == O_DISH) | (hname == O_DISH)) ? 1u : 0u;
+    const uint32_t onion = ((oname == O_ONION) | (hname == O_ONION)) ? 1u : 0u;
+    const uint32_t tomato = ((oname == O_TOMATO) | (hname == O_TOMATO)) ? 1u : 0u;
+    const uint32_t tbit = terr == T_AIR ? 0u : 1u;
+    const uint32_t tsh = ((terr - 1u) & 3u) * 8u;
+    uint4 t;
+    t.x = (terr >= 1 && terr <= 4) ? (tbit << tsh) : 0u;
+    t.y = ((terr >= 5) ? (tbit << tsh) : 0u) | (idle_on << 16) | (idle_tom << 24);
+    t.z = soup_on | (soup_tom << 8) | (remaining << 16) | (ready << 24);
+    t.w = dish | (onion << 8) | (tomato << 16) | ((urgent ? 1u : 0u) << 24);
+    return t;
+}
+
 template <int kP>
 __device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
                                                     const uint8_t *s_pots, uint32_t *obj, uint32_t *pl, const uint8_t *act)
@@ -559,6 +593,64 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // (terrain one-hot, pot / soup / item channels incl. what the player standing there holds,
     // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
     const uint32_t F = p.F, shift = 5 * P;
+    if (p.whole) {
+        // The group's whole observation slab fits one LDS tile (small layouts): zero it, let
+        // each cell-lane drop its 16 bytes into the rows of all P viewers plus the two player
+        // bytes of whoever stands there, then stream the slab out.  Three LDS round trips per
+        // launch in the dependency chain instead of three per 128-row pass.
+        uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+        const uint32_t nbytes = nw * p.block_bytes;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
+        uint8_t *tile = s_tile + mis;
+        const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
+        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
+        // (Giving a lane the cell pair 2i, 2i+1 so that each store has a wave-uniform alignment
+        // class was tried: fewer LDS stores but worse lane utilisation, 4% slower overall.)
+        for (uint32_t i = lane; i < ncells; i += kWave) {
+            const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+            const uint32_t terr = s_terrain[c];
+            const uint32_t o = s_obj[i];
+            const uint32_t who = s_cur[i];
+            const uint32_t urgent = s_flags[l];
+            const bool occupied = who != 0xFF;
+            const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
+            const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
+            const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
+            const uint4 t = cell_tail(p, terr, o, h, urgent);
+            uint32_t off = __umul24(l, p.block_bytes) + __umul24(c, F);  // row (l, viewer 0, c)
+            for (uint32_t v = 0; v < P; v++, off += plane) {
+                uint8_t *row = tile + off;
+                lds_store_tail(row + shift, t, p.tail_even ? ((mis + off + shift) & 3u) : 1u);
+                if (occupied) {
+                    const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                    row[rel] = 1;
+                    row[P + 4 * rel + w_ori] = 1;
+                }
+            }
+        }
+        wave_lds_sync();
+        const uint32_t head = min((16u - mis) & 15u, nbytes);
+        if (lane < head) gobs[lane] = tile[lane];
+        const uint32_t body = (nbytes - head) >> 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
+        uint4 *dst = reinterpret_cast<uint4 *>(gobs + head);
+        for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+            const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+            const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
+            const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
+            if (ba) stream_store(dst + ka, va);
+            if (bb) stream_store(dst + kb, vb);
+            if (bc) stream_store(dst + kc, vc);
+            if (bd) stream_store(dst + kd, vd);
+        }
+        const uint32_t done_bytes = head + (body << 4);
+        if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+        STAMP(15);
+        STAMP_REALTIME(14);
+        return;
+    }
     for (uint32_t i = lane; i < ncells; i += kWave) {
         const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
         const uint32_t terr = s_terrain[c];
@@ -566,30 +658,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint32_t who = s_cur[i];
         const uint32_t urgent = s_flags[l];
         const uint32_t h = who != 0xFF ? s_pl[(__umul24(l, P) + who) * 2 + 1] : kItemNone;
-        const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(o));
-        const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, tom = (o >> 16) & 0xFF;
-        const int32_t tick = (int8_t)(o >> 24);
-        const uint32_t hname = h & 0xFF;
-        const bool is_soup = oname == O_SOUP, in_pot = terr == T_POT;
-        const bool idle = is_soup & in_pot & (tick < 0);
-        const bool hot = is_soup & in_pot & (tick >= 0);
-        const bool plated = is_soup & !in_pot;
-        const bool hsoup = hname == O_SOUP;  // a soup in hand overrides the cell's soup channels
-        const uint32_t idle_on = idle ? on : 0u, idle_tom = idle ? tom : 0u;
-        const uint32_t soup_on = hsoup ? (h >> 8) & 0xFF : ((hot | plated) ? on : 0u);
-        const uint32_t soup_tom = hsoup ? (h >> 16) & 0xFF : ((hot | plated) ? tom : 0u);
-        const uint32_t remaining = (hot & !hsoup) ? (uint32_t)(need - tick) & 0xFF : 0u;
-        const uint32_t ready = (hsoup | plated | (hot & (tick >= need))) ? 1u : 0u;
-        const uint32_t dish = ((oname == O_DISH) | (hname == O_DISH)) ? 1u : 0u;
-        const uint32_t onion = ((oname == O_ONION) | (hname == O_ONION)) ? 1u : 0u;
-        const uint32_t tomato = ((oname == O_TOMATO) | (hname == O_TOMATO)) ? 1u : 0u;
-        const uint32_t tbit = terr == T_AIR ? 0u : 1u;
-        const uint32_t tsh = ((terr - 1u) & 3u) * 8u;
-        uint4 t;
-        t.x = (terr >= 1 && terr <= 4) ? (tbit << tsh) : 0u;
-        t.y = ((terr >= 5) ? (tbit << tsh) : 0u) | (idle_on << 16) | (idle_tom << 24);
-        t.z = soup_on | (soup_tom << 8) | (remaining << 16) | (ready << 24);
-        t.w = dish | (onion << 8) | (tomato << 16) | ((urgent ? 1u : 0u) << 24);
+        const uint4 t = cell_tail(p, terr, o, h, urgent);
         s_tail[i] = t;
     }
     wave_lds_sync();
@@ -918,6 +987,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.inv_p = P == 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)P) + 1u;  // x/1: umulhi(x, 2^32-1) == x-1 for x>0; handled in-kernel
         a.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)a.rows) + 1u;
         const uint32_t tile_bytes = (((uint32_t)kRowsPerPass * a.F + 15u) & ~15u) + 32u;
+        // Per-wave LDS.  If the group's whole observation slab fits a tile of kWholeTileMax bytes
+        // the encode is single-pass and needs no per-cell tail buffer; otherwise rows go through
+        // a kRowsPerPass-row tile fed from a 16-byte-per-cell tail buffer.
+        constexpr uint32_t kWholeTileMax = 8448;  // 4 workgroups x 4 waves x (tile + state) <= 160 KB per CU
         auto layout = [&](uint32_t wpw) {
             auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
             a.wpw = wpw;
@@ -926,8 +999,15 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.off_cur = a.off_act + up16(wpw * a.P);
             a.off_flags = a.off_cur + up16(wpw * a.C);
             a.off_tail = a.off_flags + up16(wpw);
-            a.off_tile = a.off_tail + wpw * a.C * 16;
-            a.lds_wave_stride = a.off_tile + tile_bytes;
+            const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
+            a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
+            if (a.whole) {
+                a.off_tile = a.off_tail;
+                a.lds_wave_stride = a.off_tile + whole_tile;
+            } else {
+                a.off_tile = a.off_tail + wpw * a.C * 16;
+                a.lds_wave_stride = a.off_tile + tile_bytes;
+            }
             return kConstBytes + kWavesPerBlock * a.lds_wave_stride;
         };
         // worlds per wave: as many as keep >= 4096 waves in the launch, fit 40 KB of LDS per
