@@ -1018,6 +1018,12 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             if (wpw < 1 || wpw > 64) wpw = 1;
         } else {
             while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
+            // the single-pass encode is worth more than wider groups (measured, 32768 worlds,
+            // us per launch at wpw 4 / 8: coordination_ring 14.4 / 17.6, counter_circuit 19.4 / 25.8,
+            // asymmetric_advantages 31.5 / 36.3): shrink the group until its slab fits one tile
+            uint32_t cand = wpw;
+            while (cand > 1 && (layout(cand), !a.whole)) cand >>= 1;
+            if ((layout(cand), a.whole)) wpw = cand;
         }
         while (wpw > 1 && (layout(wpw) > 65536 || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
