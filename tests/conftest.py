@@ -24,6 +24,9 @@ def oracle_lib():
 
 @pytest.fixture(scope="session")
 def hip_lib():
-    """The product library; GPU tests fail (not skip) when it is missing."""
+    """The product library (built with hipcc if the in-tree .so is missing or stale);
+    tests fail, not skip, when it cannot be had."""
     from madrona_rl_envs_playground_amd import _lib
+    if not os.environ.get("MRL_ENVS_LIB"):
+        _lib.build()
     return _lib.lib()
