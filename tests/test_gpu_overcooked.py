@@ -70,6 +70,10 @@ def test_golden_vectors(path, hip_lib):
     ("asymmetric_advantages_tomato", 80, None, 640, 200),
     ("many_player_layout", 30, 8, 33, 70),
     ("many_player_layout", 25, None, 9, 60),
+    ("multiplayer_schelling", 40, 3, 130, 120),      # odd player count: byte-wise row tails
+    ("cramped_room", 30, 1, 77, 100),                # a single player
+    ("many_player_layout", 20, 5, 40, 60),
+    ("cramped_room", 400, None, 40000, 12),          # 8 worlds per wave, ragged last group
 ])
 def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
     """Independent random actions per world; obs, reward, done and the full
