@@ -43,7 +43,6 @@ constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-recor
 constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
 constexpr int kObsRow = 672, kStateRow = 784;
 constexpr int kObsChunks = kObsRow / 16, kStateChunks = kStateRow / 16, kMaskChunks = 5;
-constexpr int kChunksPerAgent = kObsChunks + kStateChunks + kMaskChunks;  // 96
 
 // record layout (bytes); identical to oracle/hanabi_oracle.c's dump
 enum : int {
@@ -128,9 +127,12 @@ __device__ __forceinline__ uint32_t ones(uint32_t n) { return n >= 32 ? 0xFFFFFF
 
 // sim.cpp:367-379 as a bit vector: bits [0, obs_bits) = observation of `agent`,
 // bits [obs_bits, state_bits) = its own hand; enc[25] = legal moves (sim.cpp:381-444)
+// kR: compile-time rank count (5 in every configuration the reference defines, envs/hanabi_env.py:16-58)
+// so that card / R and card % R are multiply-shifts instead of runtime divisions; 0 = use p.ranks.
+template <int kR>
 __device__ void encode_agent(const HanabiParams &p, uint8_t *rec, uint32_t *enc, uint32_t agent)
 {
-    const uint32_t K = p.colors, R = p.ranks, bpc = p.bpc;
+    const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks, bpc = p.bpc;
     for (int w = 0; w < kEncWords; w++) enc[w] = 0;
     uint8_t *own = rec + R_HAND + HAND_BYTES * agent;
     uint8_t *other = rec + R_HAND + HAND_BYTES * (agent ^ 1u);
@@ -264,9 +266,10 @@ __device__ __forceinline__ void take_from_hand(const HanabiParams &p, uint8_t *r
 }
 
 // sim.cpp:596-792
+template <int kR>
 __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
 {
-    const uint32_t K = p.colors, R = p.ranks;
+    const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks;
     if (rec[R_DECK_SIZE] == 0) rec[R_TURNS] = (uint8_t)(rec[R_TURNS] - 1);
     const uint32_t actor = rec[R_CUR] & 1u;
     uint8_t *hand = rec + R_HAND + HAND_BYTES * actor;
@@ -352,9 +355,10 @@ __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
 }
 
 // sim.cpp:446-532, without the encode
+template <int kR>
 __device__ void deal_new_game(const HanabiParams &p, uint8_t *rec, uint32_t episode)
 {
-    const uint32_t K = p.colors, R = p.ranks;
+    const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks;
     for (int w = 0; w < kRecordWords; w++) reinterpret_cast<uint32_t *>(rec)[w] = 0;
     rng_of(rec) = seed_of(episode);
     uint32_t k = 0;
@@ -407,27 +411,35 @@ __device__ __forceinline__ uint32_t spread4(uint32_t bits)
     return ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
 }
 
-// phase B for one (world, agent): lanes cover the 96 16-byte chunks
-__device__ __forceinline__ void expand_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t agent, uint32_t world,
-                                             uint32_t chunk)
+// phase B for one (world, agent): kTasksPerAgent 16-byte tasks.  The state row starts with the
+// same bits as the observation row (sim.cpp:333-341), so one expansion of bits [16k, 16k+16)
+// feeds chunk k of both rows; only the chunk where the observation ends is masked differently.
+constexpr int kTasksPerAgent = kStateChunks + kMaskChunks;  // 54
+__device__ __forceinline__ uint4 spread16(uint32_t bits)
+{
+    return make_uint4(spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12));
+}
+
+__device__ __forceinline__ void expand_task(const HanabiParams &p, const uint32_t *enc, uint32_t agent, uint32_t world,
+                                            uint32_t task)
 {
     const size_t row = (size_t)agent * p.num_worlds + world;
-    if (chunk < kObsChunks + kStateChunks) {
-        const bool is_state = chunk >= kObsChunks;
-        const uint32_t k = is_state ? chunk - kObsChunks : chunk;
+    if (task < kStateChunks) {
+        const uint32_t k = task, first = k * 16u;
+        const uint32_t raw = (enc[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
         // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the
         // shifted encoding pushes past the row end is dropped (the reference writes it out of bounds)
-        const uint32_t limit = is_state ? min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE)
-                                        : min(p.obs_bits + enc[26], (uint32_t)MRL_HANABI_OBS_SIZE);
-        uint32_t bits = (enc[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
-        const uint32_t first = k * 16u;
-        if (first >= limit) bits = 0;
-        else if (first + 16u > limit) bits &= ones(limit - first);
-        const uint4 v = make_uint4(spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12));
-        uint8_t *dst = is_state ? p.state + row * kStateRow : p.obs + row * kObsRow;
-        stream_store(reinterpret_cast<uint4 *>(dst) + k, v);
+        const uint32_t state_limit = min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE);
+        const uint32_t obs_limit = min(p.obs_bits + enc[26], (uint32_t)MRL_HANABI_OBS_SIZE);
+        const uint32_t sbits = first >= state_limit ? 0u : (first + 16u > state_limit ? raw & ones(state_limit - first) : raw);
+        const uint4 sv = spread16(sbits);
+        stream_store(reinterpret_cast<uint4 *>(p.state + row * kStateRow) + k, sv);
+        if (k < kObsChunks) {
+            const uint32_t obits = first >= obs_limit ? 0u : (first + 16u > obs_limit ? raw & ones(obs_limit - first) : raw);
+            stream_store(reinterpret_cast<uint4 *>(p.obs + row * kObsRow) + k, obits == sbits ? sv : spread16(obits));
+        }
     } else {
-        const uint32_t m = chunk - (kObsChunks + kStateChunks);
+        const uint32_t m = task - kStateChunks;
         const uint32_t bits = enc[25] >> (4u * m);
         stream_store(reinterpret_cast<uint4 *>(p.mask + row * 20) + m, make_uint4(bits & 1u, (bits >> 1) & 1u, (bits >> 2) & 1u, (bits >> 3) & 1u));
     }
@@ -462,6 +474,7 @@ __device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLd
 
 // Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), p.chunk a
 // multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
+template <int kR>
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
@@ -484,10 +497,10 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
             const uint32_t actor = rec[R_CUR] & 1u;
-            apply_action(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
+            apply_action<kR>(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
             const uint32_t next = rec[R_CUR] & 1u;
             // observationSystem (:794-810): only the player to move is refreshed
-            encode_agent(p, rec, enc, next);
+            encode_agent<kR>(p, rec, enc, next);
             p.active[(size_t)next * N + world] = 1;
             p.active[(size_t)(next ^ 1u) * N + world] = 0;
             // checkDone (:812-850)
@@ -500,17 +513,17 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
             const float rew = (float)(int8_t)(score - old_score);
             p.reward[world] = rew;
             p.reward[(size_t)N + world] = rew;
-            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * p.ranks || (int8_t)rec[R_TURNS] <= 0;
+            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
             p.done[world] = over ? 1 : 0;
         }
         finished += (uint32_t)__popcll(__ballot(over));
         wave_lds_sync();
 
         // phase B: bits -> bytes for every world's player to move
-        for (uint32_t task = lane; task < nw * kChunksPerAgent; task += kWave) {
-            const uint32_t r = task / kChunksPerAgent, chunk = task - r * kChunksPerAgent;
+        for (uint32_t task = lane; task < nw * kTasksPerAgent; task += kWave) {
+            const uint32_t r = task / kTasksPerAgent, sub_task = task - r * kTasksPerAgent;
             const uint32_t agent = l.rec[r * kRecStride + R_CUR] & 1u;
-            expand_chunk(p, l.enc + r * 2 * kEncWords, agent, w0 + r, chunk);
+            expand_task(p, l.enc + r * 2 * kEncWords, agent, w0 + r, sub_task);
         }
         for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
         wave_lds_sync();
@@ -524,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
 // kAll: (re)initialise every world as episode episode_base + world (construction /
 // mrl_reseed_shard); otherwise only the worlds whose done flag is set, numbered in
 // ascending world order from *episode_base.
-template <bool kAll>
+template <bool kAll, int kR>
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
                                                            uint32_t episode_base_value, uint32_t *next_counter,
                                                            uint32_t *reset_count)
@@ -576,9 +589,9 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
             uint8_t *rec = l.rec + lane * kRecStride;
             // entries are in ascending world order, so entry k of this sub-block is the
             // (running + k)-th finished world of the step
-            deal_new_game(p, rec, base + (kAll ? world : running + entry));
-            encode_agent(p, rec, l.enc + lane * 2 * kEncWords, 0);
-            encode_agent(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
+            deal_new_game<kR>(p, rec, base + (kAll ? world : running + entry));
+            encode_agent<kR>(p, rec, l.enc + lane * 2 * kEncWords, 0);
+            encode_agent<kR>(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
             p.active[world] = 1;
             p.active[(size_t)N + world] = 0;
             if (kAll) {
@@ -590,9 +603,9 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
         wave_lds_sync();
         for (uint32_t r = 0; r < my_n; r++) {
             const uint32_t world = sub + s_list[my_first + r];
-            for (uint32_t task = lane; task < 2 * kChunksPerAgent; task += kWave) {
-                const uint32_t agent = task / kChunksPerAgent, chunk = task - agent * kChunksPerAgent;
-                expand_chunk(p, l.enc + (r * 2 + agent) * kEncWords, agent, world, chunk);
+            for (uint32_t task = lane; task < 2 * kTasksPerAgent; task += kWave) {
+                const uint32_t agent = task / kTasksPerAgent, sub_task = task - agent * kTasksPerAgent;
+                expand_task(p, l.enc + (r * 2 + agent) * kEncWords, agent, world, sub_task);
             }
             if (lane < kRecordWords)
                 p.records[(size_t)world * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
@@ -622,15 +635,22 @@ struct HanabiSim final : mrl_sim {
     {
         HanabiParams a = params;
         a.actions = actions ? actions : action;
-        hipLaunchKernelGGL(mrl_hanabi_step, dim3(grid), dim3(kBlock), 0, stream, a);
+        if (a.ranks == 5)
+            hipLaunchKernelGGL((mrl_hanabi_step<5>), dim3(grid), dim3(kBlock), 0, stream, a);
+        else
+            hipLaunchKernelGGL((mrl_hanabi_step<0>), dim3(grid), dim3(kBlock), 0, stream, a);
         MRL_HIP(hipGetLastError());
     }
 
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
-        hipLaunchKernelGGL(mrl_hanabi_reset<false>, dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                           counter + (parity ^ 1u), reset_count);
+        if (params.ranks == 5)
+            hipLaunchKernelGGL((mrl_hanabi_reset<false, 5>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
+                               counter + (parity ^ 1u), reset_count);
+        else
+            hipLaunchKernelGGL((mrl_hanabi_reset<false, 0>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
+                               counter + (parity ^ 1u), reset_count);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -643,8 +663,12 @@ struct HanabiSim final : mrl_sim {
 
     void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl_hanabi_reset<true>, dim3(grid), dim3(kBlock), 0, stream, params,
-                           (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        if (params.ranks == 5)
+            hipLaunchKernelGGL((mrl_hanabi_reset<true, 5>), dim3(grid), dim3(kBlock), 0, stream, params,
+                               (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params,
+                               (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
         MRL_HIP(hipGetLastError());
         set_episode_counter(num_worlds_total, stream);
     }
