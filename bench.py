@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--horizon", type=int, default=400)
     ap.add_argument("--gather-obs", action="store_true", help="all-gather observation shards every step (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-steps", type=int, default=1000, help="steps of the extra device-side random rollout (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--pool", type=int, default=64, help="pre-sampled action tensors cycled through")
     return ap.parse_args()
@@ -151,6 +152,21 @@ def main():
     torch.cuda.synchronize()
     kernel_ms_avg = ev0.elapsed_time(ev1) / k_launch
 
+    # extra, never `value`: the same random-policy workload with the actions drawn in the kernel and
+    # the worlds' state kept in LDS between steps (mrl_rollout_random)
+    fused = None
+    if world_size == 1 and args.fused_steps > 0:
+        sim.rollout_random(args.fused_steps, seed=99, first_step=0)
+        torch.cuda.synchronize()
+        ev0.record()
+        sim.rollout_random(args.fused_steps, seed=99, first_step=args.fused_steps)
+        ev1.record()
+        torch.cuda.synchronize()
+        fused_ms = ev0.elapsed_time(ev1)
+        fused = {"value": n * args.fused_steps / (fused_ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.fused_steps,
+                 "us_per_step": fused_ms * 1e3 / args.fused_steps,
+                 "note": "every step still writes its observation slab, rewards and dones"}
+
     if rank == 0:
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
         # inside this process); only reported when they were taken on this exact workload
@@ -184,6 +200,8 @@ def main():
                          "kernel": sim.kernel_name, "kernel_us_avg": kernel_ms_avg * 1e3,
                          "bytes_per_launch": bytes_per_launch, "launches_timed": k_launch},
         }
+        if fused is not None:
+            out["fused_random_rollout"] = fused
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)
         print(json.dumps(out), flush=True)

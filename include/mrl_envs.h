@@ -231,6 +231,17 @@ int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_strea
  * after construction.  No-op for Overcooked (its initial state is not seeded). */
 int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_total, void *hip_stream);
 
+/* Random-policy rollout on the device (Overcooked only so far):
+ * num_steps environment steps in one call, actions drawn in the kernel instead of by
+ * torch.randint + copy as in the reference harness (scripts/overcooked_example.py:99-106).
+ * The action of (world w, player q) at step index k = first_step, first_step+1, ... is
+ *     h = lo32(seed) ^ k*0x9E3779B9 ^ w*0x85EBCA6B ^ (q+1)*0xC2B2AE35 ^ hi32(seed)*0x27D4EB2F
+ *     h ^= h>>16; h *= 0x7FEB352D; h ^= h>>15; h *= 0x846CA68B; h ^= h>>16;   (all mod 2^32)
+ *     action = (h * 6) >> 32
+ * so a stream can be replayed through mrl_step.  Every step writes observation, reward and
+ * done exactly like mrl_step; after the call the ACTION tensor holds the last step's actions. */
+int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream);
+
 int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out);
 int mrl_game(const mrl_sim *sim);
 uint32_t mrl_num_worlds(const mrl_sim *sim);

@@ -138,6 +138,12 @@ int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_to
     return guarded([&] { sim->reseed_shard(world_offset, num_worlds_total, (hipStream_t)hip_stream); });
 }
 
+int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    return guarded([&] { sim->rollout_random(num_steps, seed, first_step, (hipStream_t)hip_stream); });
+}
+
 int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out)
 {
     if (int rc = mrl::need(sim)) return rc;

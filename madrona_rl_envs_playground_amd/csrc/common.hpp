@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -87,6 +88,8 @@ struct mrl_sim {
     // actions == nullptr -> read the simulator's own ACTION tensor
     virtual void phase1(const int32_t *actions, hipStream_t stream) = 0;
     virtual void phase2(const uint32_t *episode_base_dev, hipStream_t stream) = 0;
+    // num_steps, seed, first_step: the uniform random policy on the device (include/mrl_envs.h)
+    virtual void rollout_random(uint32_t, uint64_t, uint32_t, hipStream_t) { throw std::runtime_error("this game has no device-side random-policy rollout"); }
     virtual void set_episode_counter(uint32_t, hipStream_t) {}
     virtual void reseed_shard(uint32_t, uint32_t, hipStream_t) {}
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;

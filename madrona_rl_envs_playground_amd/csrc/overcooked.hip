@@ -435,6 +435,67 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
 
 // Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
+// Single-pass encode of a group's observation slab (small layouts; see the call site).
+__device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
+                                              const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
+                                              uint8_t *s_tile, uint32_t P, uint32_t w0, uint32_t nw, uint32_t lane)
+{
+    const uint32_t C = p.C, F = p.F, shift = 5 * P, ncells = nw * C;
+    // The group's whole observation slab fits one LDS tile (small layouts): zero it, let
+    // each cell-lane drop its 16 bytes into the rows of all P viewers plus the two player
+    // bytes of whoever stands there, then stream the slab out.  Three LDS round trips per
+    // launch in the dependency chain instead of three per 128-row pass.
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    const uint32_t nbytes = nw * p.block_bytes;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
+    uint8_t *tile = s_tile + mis;
+    const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
+    for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+    const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
+    // (Giving a lane the cell pair 2i, 2i+1 so that each store has a wave-uniform alignment
+    // class was tried: fewer LDS stores but worse lane utilisation, 4% slower overall.)
+    for (uint32_t i = lane; i < ncells; i += kWave) {
+        const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+        const uint32_t terr = s_terrain[c];
+        const uint32_t o = s_obj[i];
+        const uint32_t who = s_cur[i];
+        const uint32_t urgent = s_flags[l];
+        const bool occupied = who != 0xFF;
+        const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
+        const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
+        const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
+        const uint4 t = cell_tail(p, terr, o, h, urgent);
+        uint32_t off = __umul24(l, p.block_bytes) + __umul24(c, F);  // row (l, viewer 0, c)
+        for (uint32_t v = 0; v < P; v++, off += plane) {
+            uint8_t *row = tile + off;
+            lds_store_tail(row + shift, t, p.tail_even ? ((mis + off + shift) & 3u) : 1u);
+            if (occupied) {
+                const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                row[rel] = 1;
+                row[P + 4 * rel + w_ori] = 1;
+            }
+        }
+    }
+    wave_lds_sync();
+    const uint32_t head = min((16u - mis) & 15u, nbytes);
+    if (lane < head) gobs[lane] = tile[lane];
+    const uint32_t body = (nbytes - head) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
+    uint4 *dst = reinterpret_cast<uint4 *>(gobs + head);
+    for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+        const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+        const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
+        const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
+        if (ba) stream_store(dst + ka, va);
+        if (bb) stream_store(dst + kb, vb);
+        if (bc) stream_store(dst + kc, vc);
+        if (bd) stream_store(dst + kd, vd);
+    }
+    const uint32_t done_bytes = head + (body << 4);
+    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+}
+
 #ifdef MRL_DIAG
 #define STAMP(k)                                                                                               \
     do {                                                                                                       \
@@ -594,59 +655,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
-        // The group's whole observation slab fits one LDS tile (small layouts): zero it, let
-        // each cell-lane drop its 16 bytes into the rows of all P viewers plus the two player
-        // bytes of whoever stands there, then stream the slab out.  Three LDS round trips per
-        // launch in the dependency chain instead of three per 128-row pass.
-        uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
-        const uint32_t nbytes = nw * p.block_bytes;
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
-        uint8_t *tile = s_tile + mis;
-        const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
-        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-        const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
-        // (Giving a lane the cell pair 2i, 2i+1 so that each store has a wave-uniform alignment
-        // class was tried: fewer LDS stores but worse lane utilisation, 4% slower overall.)
-        for (uint32_t i = lane; i < ncells; i += kWave) {
-            const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
-            const uint32_t terr = s_terrain[c];
-            const uint32_t o = s_obj[i];
-            const uint32_t who = s_cur[i];
-            const uint32_t urgent = s_flags[l];
-            const bool occupied = who != 0xFF;
-            const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
-            const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
-            const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
-            const uint4 t = cell_tail(p, terr, o, h, urgent);
-            uint32_t off = __umul24(l, p.block_bytes) + __umul24(c, F);  // row (l, viewer 0, c)
-            for (uint32_t v = 0; v < P; v++, off += plane) {
-                uint8_t *row = tile + off;
-                lds_store_tail(row + shift, t, p.tail_even ? ((mis + off + shift) & 3u) : 1u);
-                if (occupied) {
-                    const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
-                    row[rel] = 1;
-                    row[P + 4 * rel + w_ori] = 1;
-                }
-            }
-        }
-        wave_lds_sync();
-        const uint32_t head = min((16u - mis) & 15u, nbytes);
-        if (lane < head) gobs[lane] = tile[lane];
-        const uint32_t body = (nbytes - head) >> 4;
-        const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
-        uint4 *dst = reinterpret_cast<uint4 *>(gobs + head);
-        for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
-            const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
-            const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
-            const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
-            if (ba) stream_store(dst + ka, va);
-            if (bb) stream_store(dst + kb, vb);
-            if (bc) stream_store(dst + kc, vc);
-            if (bd) stream_store(dst + kd, vd);
-        }
-        const uint32_t done_bytes = head + (body << 4);
-        if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         STAMP(15);
         STAMP_REALTIME(14);
         return;
@@ -794,6 +803,123 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     STAMP_REALTIME(14);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Random-policy rollout on the device: num_steps steps in ONE launch.
+// The reference's random-policy harness draws `randint(high=6)` per agent per step with torch and
+// copies it into the action tensor (scripts/overcooked_example.py:99-106); here the draw happens
+// in the kernel and the group's state stays in LDS between steps, so a step costs neither a launch
+// nor a state round trip through HBM -- every step still writes its full observation slab,
+// rewards and done flags (the next step overwrites them, as in the reference's harness).
+//
+// Action of (world w, player q) at global step index k:  mrl_random_action(seed, k, w, q) below --
+// a counter-based hash, so any step of the stream can be recomputed (tests replay the stream
+// through the ordinary step and compare).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mrl_random_action(uint64_t seed, uint32_t step, uint32_t world, uint32_t player)
+{
+    uint32_t h = (uint32_t)seed ^ (step * 0x9E3779B9u) ^ (world * 0x85EBCA6Bu) ^ ((player + 1u) * 0xC2B2AE35u) ^
+                 ((uint32_t)(seed >> 32) * 0x27D4EB2Fu);
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return (uint32_t)(((uint64_t)h * 6u) >> 32);  // uniform over the six actions
+}
+
+template <int kP>
+__global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout(const StepParams p, uint32_t num_steps, uint64_t seed,
+                                                                                 uint32_t first_step, int32_t *action_out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
+    const uint8_t *s_terrain = smem + kConstTerrain;
+    const uint8_t *s_times = smem + kConstTimes;
+    const uint8_t *s_values = smem + kConstValues;
+    const uint8_t *s_start = smem + kConstStart;
+    const uint8_t *s_pots = smem + kConstPots;
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
+    const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
+    uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);
+    uint8_t *s_act = wbase + p.off_act;
+    uint8_t *s_cur = wbase + p.off_cur;
+    uint8_t *s_flags = wbase + p.off_flags;
+    uint8_t *s_tile = wbase + p.off_tile;
+    const uint32_t P = kP > 0 ? (uint32_t)kP : p.P, C = p.C, N = p.num_worlds;
+    const uint32_t ncells = nw * C, nplayers = nw * P;
+
+    int32_t t = 0;
+    {
+        const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        const uint2 *g_pl = p.players + (size_t)w0 * P;
+        if (lane < nw) t = p.timestep[w0 + lane];
+        for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
+        for (uint32_t i = lane; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
+    }
+    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+    __syncthreads();
+    if (nw == 0) return;
+
+    for (uint32_t k = 0; k < num_steps; k++) {
+        if (lane < nw) {
+            uint32_t *obj = s_obj + lane * C;
+            uint32_t *pl = s_pl + lane * 2 * P;
+            uint8_t *act = s_act + lane * P;
+            const uint32_t world = w0 + lane;
+            for (uint32_t q = 0; q < P; q++) {
+                const uint32_t a = mrl_random_action(seed, first_step + k, world, q);
+                act[q] = (uint8_t)a;
+                if (k + 1 == num_steps) action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
+            }
+            int32_t reward;
+            if constexpr (kP > 0)
+                reward = transition_fixed<kP>(p, s_terrain, s_times, s_pots, obj, pl, act);
+            else
+                reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, act);
+            t += 1;
+            const bool reset_now = (int64_t)t >= p.horizon;
+            if (reset_now) {
+                t = 0;
+                for (uint32_t c = 0; c < C; c++) obj[c] = kItemNone;
+                for (uint32_t q = 0; q < P; q++) {
+                    pl[2 * q] = (uint32_t)s_start[q] | (A_NORTH << 8);
+                    pl[2 * q + 1] = kItemNone;
+                }
+            }
+            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = reward;
+            p.done[world] = (int32_t)reset_now;
+            s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+        }
+        for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        wave_lds_sync();
+        if (lane < nw)
+            for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
+        wave_lds_sync();
+        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+        wave_lds_sync();
+    }
+    // state back to HBM once, after the last step
+    uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+    for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
+    uint2 *g_pl = p.players + (size_t)w0 * P;
+    for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
+    if (lane < nw) p.timestep[w0 + lane] = t;
+}
+
+// fallback for layouts without the single-pass encode: draw into the ACTION tensor, then an ordinary step
+__global__ void mrl_overcooked_draw_actions(int32_t *action, uint32_t players, uint32_t n, uint64_t seed, uint32_t step)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)players * n) action[i] = (int32_t)mrl_random_action(seed, step, (uint32_t)(i % n), (uint32_t)(i / n));
+}
+
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -832,6 +958,27 @@ struct OvercookedSim final : mrl_sim {
 
     void phase1(const int32_t *actions, hipStream_t stream) override { launch(false, actions, stream); }
     void phase2(const uint32_t *, hipStream_t) override {}
+
+    void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
+    {
+        if (num_steps == 0) return;
+        if (params.whole) {
+            if (params.P == 2)
+                hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
+                                   params, num_steps, seed, first_step, action);
+            else
+                hipLaunchKernelGGL((mrl_overcooked_rollout<0>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
+                                   params, num_steps, seed, first_step, action);
+            MRL_HIP(hipGetLastError());
+            return;
+        }
+        const size_t count = (size_t)params.P * num_worlds;
+        for (uint32_t k = 0; k < num_steps; k++) {
+            hipLaunchKernelGGL(mrl_overcooked_draw_actions, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                               action, params.P, num_worlds, seed, first_step + k);
+            launch(false, nullptr, stream);
+        }
+    }
 
     void ensure_ids()
     {

@@ -81,6 +81,24 @@ class Tensor:
         return self._torch
 
 
+def random_action(seed, step, world, player):
+    """The device-side random policy's action for (step index, world, player): the counter-based
+    hash documented at ``mrl_rollout_random`` in include/mrl_envs.h.  Accepts numpy arrays."""
+    import numpy as np
+    m = np.uint64(0xFFFFFFFF)
+    seed = int(seed) & (2 ** 64 - 1)
+    h = (np.uint64(seed & 0xFFFFFFFF) ^ (np.uint64(step) * np.uint64(0x9E3779B9) & m) ^
+         (np.asarray(world, np.uint64) * np.uint64(0x85EBCA6B) & m) ^
+         ((np.asarray(player, np.uint64) + np.uint64(1)) * np.uint64(0xC2B2AE35) & m) ^
+         (np.uint64(seed >> 32) * np.uint64(0x27D4EB2F) & m))
+    h ^= h >> np.uint64(16)
+    h = h * np.uint64(0x7FEB352D) & m
+    h ^= h >> np.uint64(15)
+    h = h * np.uint64(0x846CA68B) & m
+    h ^= h >> np.uint64(16)
+    return ((h * np.uint64(6)) >> np.uint64(32)).astype(np.int32)
+
+
 class _Simulator:
     """Shared handle management for the three games."""
 
@@ -118,6 +136,13 @@ class _Simulator:
         rc = self._L.mrl_step_with_actions(self._handle, actions.data_ptr(), stream)
         if rc:
             _lib.check(rc)
+
+    def rollout_random(self, num_steps, seed=0, first_step=0):
+        """``num_steps`` steps under the uniform random policy, actions drawn on the
+        device (``mrl_rollout_random``; see ``random_action`` for the stream)."""
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        _lib.check(self._L.mrl_rollout_random(self._handle, int(num_steps), int(seed) & (2 ** 64 - 1), int(first_step),
+                                              stream))
 
     def step_phase1(self, actions=None):
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream

@@ -159,3 +159,54 @@ def test_rejects_bad_configs(hip_lib):
         make_sim(bad, 4)
     with pytest.raises(NotImplementedError):
         OvercookedSimulator(exec_mode=ExecMode.CPU, gpu_id=0, num_worlds=4, **params)
+
+
+@pytest.mark.parametrize("layout,horizon,cap,n,chunks", [
+    ("cramped_room", 23, None, 4099, [1, 7, 30, 2, 25]),   # crosses several horizon resets, ragged last group
+    ("cramped_room", 400, None, 40000, [16]),              # 8 worlds per wave
+    ("multiplayer_schelling", 31, 3, 130, [9, 40]),        # odd player count: generic transition
+    ("many_player_layout", 15, None, 9, [5, 20]),          # no single-pass encode: draw kernel + ordinary step
+])
+def test_device_random_rollout(layout, horizon, cap, n, chunks, hip_lib, oracle_lib):
+    """mrl_rollout_random == the oracle fed the documented action stream: obs, reward,
+    done, last actions and the full state after every chunk of fused steps."""
+    from madrona_rl_envs_playground_amd.simulators import random_action
+    params = layouts.get_base_layout_params(layout, horizon, max_num_players=cap)
+    P, C = params["num_players"], params["height"] * params["width"]
+    F = 5 * P + 16
+    seed = 0x1234_5678_9ABC_DEF1
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    sim = make_sim(params, n)
+    o = world_major(sim).view(n, P, C, F)
+    world, player = np.meshgrid(np.arange(n), np.arange(P))
+    k = 1000  # first_step offsets the stream
+    for chunk in chunks:
+        sim.rollout_random(chunk, seed=seed, first_step=k)
+        for s in range(chunk):
+            acts = random_action(seed, k + s, world, player)
+            assert acts.min() >= 0 and acts.max() <= 5
+            orc.step(acts)
+        k += chunk
+        assert np.array_equal(sim.action_tensor().to_torch().cpu().numpy()[..., 0], acts)
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ after step {k}"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward)
+        assert np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done)
+        pl, ob, ts = orc.dump()
+        assert np.array_equal(unpack_players(sim.state_players_tensor().to_torch()), pl)
+        assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob)
+        assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts)
+    # an ordinary step continues from the rollout's state
+    acts = random_action(seed, k, world, player)
+    sim.action_tensor().to_torch().copy_(torch.from_numpy(acts).cuda().view(P, n, 1))
+    sim.step()
+    orc.step(acts)
+    assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs)
+    sim.close()
+
+
+def test_rollout_unsupported_games_fail_loudly(hip_lib):
+    from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, MrlError
+    sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=8)
+    with pytest.raises(MrlError, match="random-policy rollout"):
+        sim.rollout_random(3)
+    sim.close()

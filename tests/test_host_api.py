@@ -120,3 +120,26 @@ def test_random_agent_and_spaces():
 def test_exec_mode_shim():
     assert madrona.ExecMode.CPU is ExecMode.CPU and madrona.ExecMode.CUDA is ExecMode.CUDA
     assert ExecMode.HIP is ExecMode.CUDA
+
+
+def test_random_action_stream_is_uniform_and_reproducible():
+    """The device random policy's hash (include/mrl_envs.h, mrl_rollout_random) as restated on the host."""
+    from madrona_rl_envs_playground_amd.simulators import random_action
+    world, player = np.meshgrid(np.arange(50000), np.arange(2))
+    a = random_action(7, 3, world, player)
+    assert a.dtype == np.int32 and a.shape == (2, 50000) and a.min() == 0 and a.max() == 5
+    freq = np.bincount(a.ravel(), minlength=6) / a.size
+    assert np.abs(freq - 1 / 6).max() < 0.01
+    assert np.array_equal(a, random_action(7, 3, world, player))
+    assert (a != random_action(7, 4, world, player)).mean() > 0.7
+    assert (a != random_action(8, 3, world, player)).mean() > 0.7
+    assert (a[0] != a[1]).mean() > 0.7
+    assert (a != random_action(7 + (1 << 32), 3, world, player)).mean() > 0.7
+    # known answers, computed by hand-evaluating the formula in the header with Python integers
+    def scalar(seed, k, w, q):
+        m = 0xFFFFFFFF
+        h = (seed & m) ^ (k * 0x9E3779B9 & m) ^ (w * 0x85EBCA6B & m) ^ ((q + 1) * 0xC2B2AE35 & m) ^ ((seed >> 32) * 0x27D4EB2F & m)
+        h ^= h >> 16; h = h * 0x7FEB352D & m; h ^= h >> 15; h = h * 0x846CA68B & m; h ^= h >> 16
+        return (h * 6) >> 32
+    for seed, k, w, q in [(0, 0, 0, 0), (7, 3, 49999, 1), (2 ** 64 - 1, 2 ** 32 - 1, 12345, 63)]:
+        assert int(random_action(seed, k, np.array([w]), np.array([q]))[0]) == scalar(seed, k, w, q)
