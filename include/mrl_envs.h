@@ -156,6 +156,10 @@ typedef struct mrl_hanabi_config {
  *   DONE int32 (N); ACTIVE_AGENT int32 (2,N); ACTION int32 (2,N,1);
  *   OBSERVATION int8 (2,N,658); ACTION_MASK int32 (2,N,20); REWARD float32 (2,N);
  *   WORLD_ID / AGENT_ID int32 (2,N); STATE int8 (2,N,783);
+ *   OBSERVATION, STATE and ACTION_MASK are strided views (see the strides in the
+ *   descriptor) into one array of 1536-byte blocks [state 784 | obs 672 | mask 80],
+ *   world-major with the two agents of a world back to back: one step writes whole
+ *   cache lines only.
  *   GAME uint8 (N, 176): the raw per-world game record (tests only; layout in
  *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last step. */
 enum {

@@ -28,21 +28,41 @@
 #include "common.hpp"
 #include "episode_scan.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef MRL_HANABI_WPB
+#define MRL_HANABI_WPB 4
+#endif
+#ifndef MRL_HANABI_WPW
+#define MRL_HANABI_WPW 16
+#endif
+constexpr int kWavesPerBlock = MRL_HANABI_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kWorldsPerWave = 16;
+constexpr int kWorldsPerWave = MRL_HANABI_WPW;
 constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
 
 constexpr int kHand = 5;
 constexpr int kRecordBytes = 176;
 constexpr int kRecordWords = kRecordBytes / 4;
+static_assert(kRecordWords == 44, "load_records divides by 44 with a multiply-shift");
 constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-record accesses spread over banks
 constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
-constexpr int kObsRow = 672, kStateRow = 784;
-constexpr int kObsChunks = kObsRow / 16, kStateChunks = kStateRow / 16, kMaskChunks = 5;
+// Output rows in HBM: everything one agent of one world receives from a step is ONE 1536-byte
+// block [state 784 | observation 672 | legal-move mask 80], the two agents of a world back to
+// back.  A wave's 16 worlds are 48 KB of contiguous blocks, written with full 1 KB wave stores
+// that cover whole 128-byte lines; the exported tensors are strided views into the blocks.
+// (Separate obs / state / mask arrays with 672 / 784 / 80-byte rows were measured first: every
+// row end shares a line with the next row, the 80-byte mask rows most of all -- dropping the
+// mask stores alone, 5 % of the bytes, took 5 us off a 24 us kernel.)
+constexpr int kObsRow = 672, kStateRow = 784, kMaskRow = 80;
+constexpr int kAgentBlock = kStateRow + kObsRow + kMaskRow;  // 1536
+constexpr int kWorldBlock = 2 * kAgentBlock;                 // 3072
+constexpr int kStateChunks = kStateRow / 16, kObsChunks = kObsRow / 16, kAgentChunks = kAgentBlock / 16;  // 49, 42, 96
+static_assert(kAgentBlock % 128 == 0, "agent blocks are whole cache lines");
 
 // record layout (bytes); identical to oracle/hanabi_oracle.c's dump
 enum : int {
@@ -63,22 +83,42 @@ struct HanabiParams {
     uint32_t off_flags, off_deck, off_fireworks, off_info, off_life, off_discard, off_last, off_know;
     uint32_t obs_bits, state_bits;
     uint32_t *records;   // N x 44 words
-    uint8_t *obs;        // 2 x N x 672
-    uint8_t *state;      // 2 x N x 784
-    int32_t *mask;       // 2 x N x 20
+    uint8_t *rows;       // N x 2 x kAgentBlock (state | obs | mask per agent)
     int32_t *active;     // 2 x N
     float *reward;       // 2 x N
     int32_t *done;       // N
     const int32_t *actions;  // 2 x N
     uint32_t *block_counts;
     uint32_t chunk;  // worlds per workgroup (multiple of kWorldsPerBlock)
+#ifdef MRL_DIAG
+    unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps (first sub-block)
+#endif
 };
+
+#ifdef MRL_DIAG
+#define STAMP(k)                                                                                                  \
+    do {                                                                                                          \
+        if (p.stamps && lane == 0 && sub == blockIdx.x * p.chunk)                                                 \
+            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+#define STAMP_REALTIME(k)                                                                                         \
+    do {                                                                                                          \
+        if (p.stamps && lane == 0 && sub == blockIdx.x * p.chunk)                                                 \
+            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#else
+#define STAMP(k) ((void)0)
+#define STAMP_REALTIME(k) ((void)0)
+#endif
 
 __device__ __forceinline__ void wave_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // Cross-lane hand-off through LDS inside ONE wave: DS instructions of a wave execute in issue
+    // order, so only the compiler has to keep the order.  (A wavefront-scope release/acquire
+    // fence is lowered with s_waitcnt vmcnt(0): the wave would sit out every row store of the
+    // expansion before storing its records.)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ uint32_t seed_of(uint32_t episode)
@@ -119,7 +159,9 @@ __device__ __forceinline__ void put(uint32_t *enc, uint32_t off, uint32_t nbits,
     const uint32_t w = off >> 5, s = off & 31;
     const uint32_t lo = value << s, hi = s ? value >> (32u - s) : 0u;
     const uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(enc + w);  // low 32 bits of a shared pointer = LDS offset
-    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" : : "v"(addr), "v"(lo), "v"(hi) : "memory");
+    // no "memory" clobber: the bit vector is only ever touched by these ORs between the two compiler
+    // barriers in encode_agent, so the record reads around a put stay free to be scheduled early
+    asm volatile("ds_or_b32 %0, %1\n\tds_or_b32 %0, %2 offset:4" : : "v"(addr), "v"(lo), "v"(hi));
     (void)nbits;
 }
 
@@ -134,6 +176,7 @@ __device__ void encode_agent(const HanabiParams &p, uint8_t *rec, uint32_t *enc,
 {
     const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks, bpc = p.bpc;
     for (int w = 0; w < kEncWords; w++) enc[w] = 0;
+    asm volatile("" ::: "memory");  // zero-fill is issued before the first OR (DS ops of a wave execute in order)
     uint8_t *own = rec + R_HAND + HAND_BYTES * agent;
     uint8_t *other = rec + R_HAND + HAND_BYTES * (agent ^ 1u);
     const uint32_t own_size = own[H_SIZE], other_size = other[H_SIZE];
@@ -241,7 +284,183 @@ __device__ void encode_agent(const HanabiParams &p, uint8_t *rec, uint32_t *enc,
             legal |= 1u << (2 * kHand + K + rk);
         }
     }
+    asm volatile("" ::: "memory");
     enc[25] = legal & 0xFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same encoding for the full game (5 colours, 5 ranks, 8 information and 3 life tokens --
+// envs/hanabi_env.py:16-27, the configuration every benchmark uses), with every section offset a
+// compile-time constant: the record is read from LDS once (44 words, one wait), the 783 bits are
+// assembled in registers with shifts at constant positions, and 27 words go back to LDS.  The
+// generic encoder above issues ~50 read-modify-write puts with runtime offsets and ~56 waits on
+// LDS reads; measured per wave 5.7 us for it against FILL_ME us for this one.
+//
+// Sections after the information tokens move up by `excess` (see above); they are assembled
+// relative to bit 200 and merged with one funnel shift per word.
+// ---------------------------------------------------------------------------------------------
+namespace full_game {
+constexpr uint32_t kBpc = 25, kK = 5, kRk = 5;
+constexpr uint32_t kOffFlags = 125, kOffDeck = 127, kOffFireworks = 167, kOffInfo = 192, kOffLife = 200;
+// relative to kOffLife (+ excess)
+constexpr uint32_t kRelDiscard = 3, kRelLast = 53, kRelKnow = 108, kRelOwnHand = 458, kRelEnd = 583;
+static_assert(kOffLife + kRelKnow + 2 * kHand * (kBpc + kK + kRk) == MRL_HANABI_OBS_SIZE, "observation layout");
+static_assert(kOffLife + kRelEnd == MRL_HANABI_STATE_SIZE, "state layout");
+constexpr int kLoWords = 7, kHiWords = 19;
+
+// OR the low `width` bits of v into a register-resident bit vector at a position that is a
+// constant after unrolling (so w[...] stays in registers)
+template <int NW>
+__device__ __forceinline__ void orbits(uint32_t (&w)[NW], uint32_t off, uint32_t width, uint32_t v)
+{
+    const uint32_t i = off >> 5, s = off & 31u;
+    w[i] |= v << s;
+    if (s + width > 32u) w[i + 1] |= v >> (32u - s);
+}
+__device__ __forceinline__ uint32_t byte_at(const uint32_t (&r)[kRecordWords], uint32_t byte) { return (r[byte >> 2] >> ((byte & 3u) * 8u)) & 0xFFu; }
+}  // namespace full_game
+
+__device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t agent)
+{
+    using namespace full_game;
+    uint32_t r[kRecordWords];
+#pragma unroll
+    for (int w = 0; w < kRecordWords; w++) r[w] = reinterpret_cast<const uint32_t *>(rec)[w];
+    // hands: own = the encoded agent's, other = the partner's (9 words each)
+    uint32_t own[9], other[9];
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        const uint32_t h0 = r[R_HAND / 4 + w], h1 = r[(R_HAND + HAND_BYTES) / 4 + w];
+        own[w] = agent ? h1 : h0;
+        other[w] = agent ? h0 : h1;
+    }
+    // bytes of a hand: cards 0..4, size 5, known colour 6..10, known rank 11..15; plausibility words 4..8
+    auto hbyte = [](const uint32_t (&h)[9], uint32_t b) { return (h[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu; };
+    const uint32_t own_size = hbyte(own, H_SIZE), other_size = hbyte(other, H_SIZE);
+
+    uint32_t lo[kLoWords], hi[kHiWords];
+#pragma unroll
+    for (int w = 0; w < kLoWords; w++) lo[w] = 0;
+#pragma unroll
+    for (int w = 0; w < kHiWords; w++) hi[w] = 0;
+
+    // partner hand + "short hand" flags (:54-90)
+#pragma unroll
+    for (uint32_t c = 0; c < kHand; c++) orbits(lo, c * kBpc, kBpc, c < other_size ? 1u << (hbyte(other, H_CARDS + c) & 31u) : 0u);
+    orbits(lo, kOffFlags, 2, (own_size < kHand ? 1u : 0u) | (other_size < kHand ? 2u : 0u));
+    // board (:92-135)
+    const uint32_t deck = min(byte_at(r, R_DECK_SIZE), 40u);
+    orbits(lo, kOffDeck, 32, ones(min(deck, 32u)));
+    orbits(lo, kOffDeck + 32, 8, deck > 32u ? ones(deck - 32u) : 0u);
+    uint32_t fw = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kK; c++) {
+        const uint32_t f = byte_at(r, R_FIREWORKS + c);
+        fw |= (f >= 1 && f <= kRk) ? 1u << (c * kRk + f - 1) : 0u;
+    }
+    orbits(lo, kOffFireworks, 25, fw);
+    const uint32_t info = byte_at(r, R_INFO);
+    const uint32_t info_now = min(info, 13u);
+    const uint32_t excess = info_now > 8u ? info_now - 8u : 0u;
+    orbits(lo, kOffInfo, 13, ones(info_now));
+
+    // everything below is placed relative to bit 200 + excess
+    orbits(hi, 0, 3, ones(min(byte_at(r, R_LIFE), 3u)));
+    // discards (:137-156)
+#pragma unroll
+    for (uint32_t c = 0; c < kK; c++) {
+        uint32_t bits = 0;
+        bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 0), 3u));
+        bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 1), 2u)) << 3;
+        bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 2), 2u)) << 5;
+        bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 3), 2u)) << 7;
+        bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 4), 1u)) << 9;
+        orbits(hi, kRelDiscard + c * 2 * kRk, 10, bits);
+    }
+    // last action (:158-289)
+    {
+        const uint32_t move = byte_at(r, R_LM_MOVE);
+        const int32_t lm_player = (int8_t)byte_at(r, R_LM_PLAYER);
+        const uint32_t lm_color = byte_at(r, R_LM_COLOR), lm_rank = byte_at(r, R_LM_RANK), lm_index = byte_at(r, R_LM_INDEX);
+        const bool hint = move == MV_REVEAL_COLOR || move == MV_REVEAL_RANK;
+        const bool card = move == MV_PLAY || move == MV_DISCARD;
+        uint32_t v = 0;
+        v |= lm_player != -1 ? 1u << (((int32_t)agent - lm_player + 2) & 1) : 0u;
+        v |= move < 4 ? (1u << (2u + ((0x03020001u >> (8u * move)) & 0xFFu))) : 0u;
+        v |= hint ? 1u << (6 + (((int32_t)agent - (int32_t)(int8_t)byte_at(r, R_LM_TARGET) + 2) & 1)) : 0u;
+        v |= (move == MV_REVEAL_COLOR && lm_color < kK) ? 1u << (8u + lm_color) : 0u;
+        v |= (move == MV_REVEAL_RANK && lm_rank < kRk) ? 1u << (13u + lm_rank) : 0u;
+        orbits(hi, kRelLast, 18, v);
+        uint32_t v2 = hint ? byte_at(r, R_LM_REVEAL) & 31u : 0u;
+        v2 |= (card && lm_index < kHand) ? 1u << (kHand + lm_index) : 0u;
+        orbits(hi, kRelLast + 18, 10, v2);
+        const uint32_t id = lm_color * kRk + lm_rank;
+        orbits(hi, kRelLast + 28, 25, (card && id < kBpc) ? 1u << id : 0u);
+        orbits(hi, kRelLast + 53, 2,
+               move == MV_PLAY ? (byte_at(r, R_LM_SCORED) ? 1u : 0u) | (byte_at(r, R_LM_INFOTOK) ? 2u : 0u) : 0u);
+    }
+    // card knowledge (:291-331): own hand first, then the partner's
+#pragma unroll
+    for (uint32_t i = 0; i < 2; i++) {
+#pragma unroll
+        for (uint32_t c = 0; c < kHand; c++) {
+            const uint32_t size = i == 0 ? own_size : other_size;
+            const uint32_t plaus = i == 0 ? own[4 + c] : other[4 + c];
+            const uint32_t kcb = i == 0 ? hbyte(own, H_KCOLOR + c) : hbyte(other, H_KCOLOR + c);
+            const uint32_t kkb = i == 0 ? hbyte(own, H_KRANK + c) : hbyte(other, H_KRANK + c);
+            const bool have = c < size;
+            const uint32_t base = kRelKnow + (i * kHand + c) * (kBpc + kK + kRk);
+            orbits(hi, base, kBpc, (have && ((plaus >> i) & 1u)) ? ones(kBpc) : 0u);  // sim.cpp:311: bit <i>, not bit <v>
+            uint32_t kr = 0;
+            kr |= kcb < kK ? 1u << kcb : 0u;          // 0xFF = unknown
+            kr |= kkb < kRk ? 1u << (kK + kkb) : 0u;
+            orbits(hi, base + kBpc, kK + kRk, have ? kr : 0u);
+        }
+    }
+    // state tail: own hand (:343-365)
+#pragma unroll
+    for (uint32_t c = 0; c < kHand; c++) orbits(hi, kRelOwnHand + c * kBpc, kBpc, c < own_size ? 1u << (hbyte(own, H_CARDS + c) & 31u) : 0u);
+
+    // legal moves (:381-444)
+    uint32_t legal = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        legal |= (i < own_size && info < 8u) ? 1u << i : 0u;
+        legal |= i < own_size ? 1u << (kHand + i) : 0u;
+    }
+    uint32_t hints = 0;
+#pragma unroll
+    for (uint32_t n = 0; n < kHand; n++) {  // all five slots, whatever the hand size (:416-417)
+        const uint32_t cardv = hbyte(other, H_CARDS + n);
+        const uint32_t col = (cardv * 205u) >> 10, rk = cardv - col * 5u;  // exact for cardv < 1024
+        hints |= col < kK ? 1u << (2 * kHand + col) : 0u;
+        hints |= 1u << (2 * kHand + kK + rk);
+    }
+    legal |= info > 0 ? hints : 0u;
+
+    // merge: words 0..6 from lo, the relative part shifted up by 200 + excess = 6 words + (8 + excess) bits
+    const uint32_t sh = 8u + excess;  // 8..13
+    uint32_t out[25];
+#pragma unroll
+    for (int w = 0; w < 6; w++) out[w] = lo[w];
+    out[6] = lo[6] | (hi[0] << sh);
+#pragma unroll
+    for (int w = 1; w < kHiWords; w++) out[6 + w] = __builtin_amdgcn_alignbit(hi[w], hi[w - 1], 32u - sh);
+#pragma unroll
+    for (int w = 0; w < 25; w++) enc[w] = out[w];
+    enc[25] = legal & 0xFFFFFu;
+    enc[26] = excess;
+}
+
+// kV selects the code variant: 0 = any configuration (runtime rank count), 1 = five ranks,
+// 2 = the full game (encode_agent_full)
+template <int kV>
+__device__ __forceinline__ void encode_variant(const HanabiParams &p, uint8_t *rec, uint32_t *enc, uint32_t agent)
+{
+    if constexpr (kV == 2)
+        encode_agent_full(rec, enc, agent);
+    else
+        encode_agent<(kV ? 5 : 0)>(p, rec, enc, agent);
 }
 
 // sim.cpp:567-594
@@ -391,18 +610,27 @@ __device__ void deal_new_game(const HanabiParams &p, uint8_t *rec, uint32_t epis
     }
 }
 
-// 16-byte write-through (sc1) store: the observation / state / mask rows are written once per
+// 16-byte write-through (sc1) stores: the observation / state / mask rows are written once per
 // step and not read by these kernels; plain stores would pile up dirty in L2 until the
 // end-of-kernel write-back (measured on the Overcooked kernel: 14.0 -> 11.8 us per launch).
+// Issued as raw buffer stores over ONE ROW: the compiler knows them (an inline-asm store is
+// invisible to its s_waitcnt bookkeeping, and a stale `vmcnt(0)` in the expansion loop then
+// waits for every store of the previous iteration: 2 300 cycles per iteration measured), and
+// lanes whose 16 bytes start past the row end are dropped by the buffer bounds check, so the
+// expansion has no per-lane branches.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_store(uint4 *dst, const uint4 &v)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_resource(void *row_base, uint32_t row_bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(row_base, 0, (int)row_bytes, 0x00020000);
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t row, uint32_t byte_offset, const uint4 &v)
 {
     u32x4 r;
     r.x = v.x;
     r.y = v.y;
     r.z = v.z;
     r.w = v.w;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(r) : "memory");
+    __builtin_amdgcn_raw_buffer_store_b128(r, row, (int)byte_offset, 0, 16);  // aux bit 4 = sc1
 }
 
 __device__ __forceinline__ uint32_t spread4(uint32_t bits)
@@ -411,38 +639,39 @@ __device__ __forceinline__ uint32_t spread4(uint32_t bits)
     return ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
 }
 
-// phase B for one (world, agent): kTasksPerAgent 16-byte tasks.  The state row starts with the
-// same bits as the observation row (sim.cpp:333-341), so one expansion of bits [16k, 16k+16)
-// feeds chunk k of both rows; only the chunk where the observation ends is masked differently.
-constexpr int kTasksPerAgent = kStateChunks + kMaskChunks;  // 54
 __device__ __forceinline__ uint4 spread16(uint32_t bits)
 {
     return make_uint4(spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12));
 }
 
-__device__ __forceinline__ void expand_task(const HanabiParams &p, const uint32_t *enc, uint32_t agent, uint32_t world,
-                                            uint32_t task)
+// Phase B: chunk `ch` (16 bytes) of one agent block from that agent's bit vector.  Chunks 0..48
+// are the state row, 49..90 the observation row (the same leading bits, sim.cpp:333-341, cut at
+// the observation's end), 91..95 the legal-move mask as five int32x4.
+__device__ __forceinline__ uint32_t clip16(uint32_t raw, uint32_t first, uint32_t limit)
 {
-    const size_t row = (size_t)agent * p.num_worlds + world;
-    if (task < kStateChunks) {
-        const uint32_t k = task, first = k * 16u;
-        const uint32_t raw = (enc[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu;
-        // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the
-        // shifted encoding pushes past the row end is dropped (the reference writes it out of bounds)
-        const uint32_t state_limit = min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE);
-        const uint32_t obs_limit = min(p.obs_bits + enc[26], (uint32_t)MRL_HANABI_OBS_SIZE);
-        const uint32_t sbits = first >= state_limit ? 0u : (first + 16u > state_limit ? raw & ones(state_limit - first) : raw);
-        const uint4 sv = spread16(sbits);
-        stream_store(reinterpret_cast<uint4 *>(p.state + row * kStateRow) + k, sv);
-        if (k < kObsChunks) {
-            const uint32_t obits = first >= obs_limit ? 0u : (first + 16u > obs_limit ? raw & ones(obs_limit - first) : raw);
-            stream_store(reinterpret_cast<uint4 *>(p.obs + row * kObsRow) + k, obits == sbits ? sv : spread16(obits));
-        }
-    } else {
-        const uint32_t m = task - kStateChunks;
-        const uint32_t bits = enc[25] >> (4u * m);
-        stream_store(reinterpret_cast<uint4 *>(p.mask + row * 20) + m, make_uint4(bits & 1u, (bits >> 1) & 1u, (bits >> 2) & 1u, (bits >> 3) & 1u));
+    // bits of [first, first + 16) that lie below `limit`
+    const int32_t room = (int32_t)limit - (int32_t)first;
+    return room >= 16 ? raw : (room <= 0 ? 0u : raw & ((1u << room) - 1u));
+}
+
+__device__ __forceinline__ uint4 agent_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t ch)
+{
+    const bool is_state = ch < kStateChunks;
+    const uint32_t k = is_state ? ch : ch - kStateChunks;  // 16-bit piece of the bit vector (meaningless for mask chunks)
+    const uint32_t word = enc[min(k >> 1, 24u)];
+    const uint32_t legal = enc[25];
+    // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the
+    // shifted encoding pushes past the row end is dropped (the reference writes it out of bounds)
+    const uint32_t excess = enc[26];
+    const uint32_t limit = is_state ? min(p.state_bits + excess, (uint32_t)MRL_HANABI_STATE_SIZE)
+                                    : min(p.obs_bits + excess, (uint32_t)MRL_HANABI_OBS_SIZE);
+    const uint32_t raw = (word >> ((k & 1u) * 16u)) & 0xFFFFu;
+    uint4 v = spread16(clip16(raw, k * 16u, limit));
+    if (ch >= kStateChunks + kObsChunks) {
+        const uint32_t bits = legal >> (4u * (ch - (kStateChunks + kObsChunks)));
+        v = make_uint4(bits & 1u, (bits >> 1) & 1u, (bits >> 2) & 1u, (bits >> 3) & 1u);
     }
+    return v;
 }
 
 struct WaveLds {
@@ -460,9 +689,21 @@ __device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
 
 __device__ __forceinline__ void load_records(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t nw, uint32_t lane)
 {
-    for (uint32_t i = lane; i < nw * kRecordWords; i += kWave) {
-        const uint32_t r = i / kRecordWords, k = i - r * kRecordWords;
-        reinterpret_cast<uint32_t *>(l.rec + r * kRecStride)[k] = p.records[(size_t)w0 * kRecordWords + i];
+    // all global loads of the wave's records are in flight before the first LDS write
+    constexpr int kRounds = (kWorldsPerWave * kRecordWords + kWave - 1) / kWave;
+    const uint32_t total = nw * kRecordWords;
+    const uint32_t *src = p.records + (size_t)w0 * kRecordWords;
+    uint32_t v[kRounds];
+#pragma unroll
+    for (int k = 0; k < kRounds; k++) {
+        const uint32_t i = lane + k * kWave;
+        v[k] = i < total ? src[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kRounds; k++) {
+        const uint32_t i = lane + k * kWave;
+        const uint32_t r = (i * 2979u) >> 17, w = i - r * kRecordWords;  // i / 44, exact for i < 4096
+        if (i < total) reinterpret_cast<uint32_t *>(l.rec + r * kRecStride)[w] = v[k];
     }
 }
 
@@ -474,9 +715,12 @@ __device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLd
 
 // Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), p.chunk a
 // multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
-template <int kR>
-__global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
+// four waves per SIMD: 65536 worlds = 4096 waves are then resident in one go (at 132 VGPRs, what
+// the compiler picks unasked, a quarter of the workgroups start only when the first ones finish)
+template <int kV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) mrl_hanabi_step(const HanabiParams p)
 {
+    constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
     const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -488,19 +732,32 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
     for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {
         const uint32_t w0 = sub + wib * kWorldsPerWave;
         const uint32_t nw = w0 < chunk_end ? min((uint32_t)kWorldsPerWave, chunk_end - w0) : 0u;
+        STAMP(0);
+        STAMP_REALTIME(13);
+        // both agents' actions are fetched with the record (the actor is only known once the
+        // record is in LDS; a dependent global load there costs a full HBM latency in phase A)
+        int32_t act0 = 0, act1 = 0;
+        if (lane < nw) {
+            act0 = p.actions[w0 + lane];
+            act1 = p.actions[(size_t)N + w0 + lane];
+        }
         load_records(p, l, w0, nw, lane);
         wave_lds_sync();
+        STAMP(1);
 
-        bool over = false;
+        bool over = false, next_is_1 = false;
         if (lane < nw) {
             uint8_t *rec = l.rec + lane * kRecStride;
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
             const uint32_t actor = rec[R_CUR] & 1u;
-            apply_action<kR>(p, rec, (uint32_t)p.actions[(size_t)actor * N + world]);
+            apply_action<kR>(p, rec, (uint32_t)(actor ? act1 : act0));
+            STAMP(2);
             const uint32_t next = rec[R_CUR] & 1u;
+            next_is_1 = next != 0;
             // observationSystem (:794-810): only the player to move is refreshed
-            encode_agent<kR>(p, rec, enc, next);
+            encode_variant<kV>(p, rec, enc, next);
+            STAMP(3);
             p.active[(size_t)next * N + world] = 1;
             p.active[(size_t)(next ^ 1u) * N + world] = 0;
             // checkDone (:812-850)
@@ -517,31 +774,46 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_step(const HanabiParams p)
             p.done[world] = over ? 1 : 0;
         }
         finished += (uint32_t)__popcll(__ballot(over));
+        const unsigned long long movers = __ballot(next_is_1);
         wave_lds_sync();
+        STAMP(4);
 
-        // phase B: bits -> bytes for every world's player to move
-        for (uint32_t task = lane; task < nw * kTasksPerAgent; task += kWave) {
-            const uint32_t r = task / kTasksPerAgent, sub_task = task - r * kTasksPerAgent;
-            const uint32_t agent = l.rec[r * kRecStride + R_CUR] & 1u;
-            expand_task(p, l.enc + r * 2 * kEncWords, agent, w0 + r, sub_task);
+        // phase B: bits -> bytes for every world's player to move; the wave's worlds are one
+        // contiguous run of blocks, so a lane's target is a 32-bit offset from a scalar base
+        {
+            const uint32_t w0s = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
+            const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0s * kWorldBlock, nw * kWorldBlock);
+            for (uint32_t f = lane; f < nw * kAgentChunks; f += kWave) {
+                const uint32_t r = (f * 2731u) >> 18, ch = f - r * kAgentChunks;  // f / 96, exact for f < 6144
+                const uint32_t agent = (uint32_t)(movers >> r) & 1u;
+                row_store(out, r * kWorldBlock + agent * kAgentBlock + ch * 16u, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
+            }
         }
+        STAMP(5);
         for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
         wave_lds_sync();
+        STAMP(6);
+        STAMP_REALTIME(14);
     }
 
     if (lane == 0) s_counts[wib] = finished;
     __syncthreads();
-    if (threadIdx.x == 0) p.block_counts[blockIdx.x] = s_counts[0] + s_counts[1] + s_counts[2] + s_counts[3];
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
+        p.block_counts[blockIdx.x] = total;
+    }
 }
 
 // kAll: (re)initialise every world as episode episode_base + world (construction /
 // mrl_reseed_shard); otherwise only the worlds whose done flag is set, numbered in
 // ascending world order from *episode_base.
-template <bool kAll, int kR>
+template <bool kAll, int kV>
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
                                                            uint32_t episode_base_value, uint32_t *next_counter,
                                                            uint32_t *reset_count)
 {
+    constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
     __shared__ uint32_t s_part[2 * kWavesPerBlock];
@@ -590,8 +862,8 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
             // entries are in ascending world order, so entry k of this sub-block is the
             // (running + k)-th finished world of the step
             deal_new_game<kR>(p, rec, base + (kAll ? world : running + entry));
-            encode_agent<kR>(p, rec, l.enc + lane * 2 * kEncWords, 0);
-            encode_agent<kR>(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
+            encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, 0);
+            encode_variant<kV>(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
             p.active[world] = 1;
             p.active[(size_t)N + world] = 0;
             if (kAll) {
@@ -603,9 +875,12 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
         wave_lds_sync();
         for (uint32_t r = 0; r < my_n; r++) {
             const uint32_t world = sub + s_list[my_first + r];
-            for (uint32_t task = lane; task < 2 * kTasksPerAgent; task += kWave) {
-                const uint32_t agent = task / kTasksPerAgent, sub_task = task - agent * kTasksPerAgent;
-                expand_task(p, l.enc + (r * 2 + agent) * kEncWords, agent, world, sub_task);
+            const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)world);
+            const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)ws * kWorldBlock, kWorldBlock);
+#pragma unroll
+            for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {  // both agents: 3 full wave stores
+                const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
+                row_store(out, f * 16u, agent_chunk(p, l.enc + (r * 2 + agent) * kEncWords, f - agent * kAgentChunks));
             }
             if (lane < kRecordWords)
                 p.records[(size_t)world * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
@@ -630,27 +905,37 @@ struct HanabiSim final : mrl_sim {
     int32_t *action = nullptr, *world_id = nullptr, *agent_id = nullptr;
     uint32_t *counter = nullptr, *reset_count = nullptr;
     uint32_t parity = 0;
+    int variant = 0;  // code variant of the kernels (see encode_variant)
 
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
         HanabiParams a = params;
         a.actions = actions ? actions : action;
-        if (a.ranks == 5)
-            hipLaunchKernelGGL((mrl_hanabi_step<5>), dim3(grid), dim3(kBlock), 0, stream, a);
-        else
-            hipLaunchKernelGGL((mrl_hanabi_step<0>), dim3(grid), dim3(kBlock), 0, stream, a);
+        switch (variant) {
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step<2>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step<1>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step<0>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+        }
         MRL_HIP(hipGetLastError());
     }
 
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
-        if (params.ranks == 5)
-            hipLaunchKernelGGL((mrl_hanabi_reset<false, 5>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
+        switch (variant) {
+        case 2:
+            hipLaunchKernelGGL((mrl_hanabi_reset<false, 2>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
                                counter + (parity ^ 1u), reset_count);
-        else
+            break;
+        case 1:
+            hipLaunchKernelGGL((mrl_hanabi_reset<false, 1>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
+                               counter + (parity ^ 1u), reset_count);
+            break;
+        default:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 0>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
                                counter + (parity ^ 1u), reset_count);
+            break;
+        }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -663,12 +948,13 @@ struct HanabiSim final : mrl_sim {
 
     void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
     {
-        if (params.ranks == 5)
-            hipLaunchKernelGGL((mrl_hanabi_reset<true, 5>), dim3(grid), dim3(kBlock), 0, stream, params,
-                               (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        else
-            hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params,
-                               (const uint32_t *)nullptr, world_offset, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        const uint32_t *none = nullptr;
+        uint32_t *no_out = nullptr;
+        switch (variant) {
+        case 2: hipLaunchKernelGGL((mrl_hanabi_reset<true, 2>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_reset<true, 1>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
+        }
         MRL_HIP(hipGetLastError());
         set_episode_counter(num_worlds_total, stream);
     }
@@ -681,18 +967,25 @@ struct HanabiSim final : mrl_sim {
         case MRL_HANABI_ACTIVE_AGENT: *out = mrl::make_desc(params.active, MRL_INT32, device, {2, N}); return true;
         case MRL_HANABI_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {2, N, 1}); return true;
         case MRL_HANABI_OBSERVATION:
-            *out = mrl::make_desc(params.obs, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {N * kObsRow, kObsRow, 1});
+            *out = mrl::make_desc(params.rows + kStateRow, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {kAgentBlock, kWorldBlock, 1});
             return true;
-        case MRL_HANABI_ACTION_MASK: *out = mrl::make_desc(params.mask, MRL_INT32, device, {2, N, 20}); return true;
+        case MRL_HANABI_ACTION_MASK:
+            *out = mrl::make_desc(params.rows + kStateRow + kObsRow, MRL_INT32, device, {2, N, 20}, {kAgentBlock / 4, kWorldBlock / 4, 1});
+            return true;
         case MRL_HANABI_REWARD: *out = mrl::make_desc(params.reward, MRL_FLOAT32, device, {2, N}); return true;
         case MRL_HANABI_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {2, N}); return true;
         case MRL_HANABI_AGENT_ID: *out = mrl::make_desc(agent_id, MRL_INT32, device, {2, N}); return true;
         case MRL_HANABI_STATE:
-            *out = mrl::make_desc(params.state, MRL_INT8, device, {2, N, MRL_HANABI_STATE_SIZE},
-                                  {N * kStateRow, kStateRow, 1});
+            *out = mrl::make_desc(params.rows, MRL_INT8, device, {2, N, MRL_HANABI_STATE_SIZE}, {kAgentBlock, kWorldBlock, 1});
             return true;
         case MRL_HANABI_GAME: *out = mrl::make_desc(params.records, MRL_UINT8, device, {N, kRecordBytes}); return true;
         case MRL_HANABI_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+#ifdef MRL_DIAG
+        case 14:
+            if (!params.stamps) return false;
+            *out = mrl::make_desc(params.stamps, MRL_UINT8, device, {(int64_t)grid * kWavesPerBlock * 16 * 8});
+            return true;
+#endif
         default: return false;
         }
     }
@@ -750,6 +1043,8 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         a.max_info = cfg->max_information_tokens;
         a.max_life = cfg->max_life_tokens;
         a.bpc = K * R;
+        sim->variant = (K == 5 && R == 5 && a.max_info == 8 && a.max_life == 3) ? 2 : (R == 5 ? 1 : 0);
+        if (const char *env = getenv("MRL_HANABI_VARIANT")) sim->variant = std::min(sim->variant, atoi(env));  // tests: force the generic encoders
         a.max_deck = (4 + (R - 2) * 2) * K - 2 * kHand;
         a.off_flags = kHand * a.bpc;
         a.off_deck = a.off_flags + 2;
@@ -766,13 +1061,14 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
             throw HipError{MRL_ERR_INVALID};
         }
         a.records = sim->arena.alloc<uint32_t>((size_t)N * kRecordWords);
-        a.obs = sim->arena.alloc<uint8_t>((size_t)2 * N * kObsRow);
-        a.state = sim->arena.alloc<uint8_t>((size_t)2 * N * kStateRow);
-        a.mask = sim->arena.alloc<int32_t>((size_t)2 * N * 20);
+        a.rows = sim->arena.alloc<uint8_t>((size_t)N * kWorldBlock);
         a.active = sim->arena.alloc<int32_t>((size_t)2 * N);
         a.reward = sim->arena.alloc<float>((size_t)2 * N);
         a.done = sim->arena.alloc<int32_t>(N);
         a.block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+#ifdef MRL_DIAG
+        a.stamps = getenv("MRL_STAMPS") ? sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16) : nullptr;
+#endif
         sim->action = sim->arena.alloc<int32_t>((size_t)2 * N);
         sim->world_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
         sim->agent_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);

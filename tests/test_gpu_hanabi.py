@@ -97,3 +97,43 @@ def test_sharded_episode_numbering(hip_lib, oracle_lib):
 def test_rejects_bad_config(hip_lib):
     with pytest.raises(RuntimeError):
         make(dict(FULL, players=3), 8)
+
+
+def test_full_game_encoder_matches_generic_encoder(hip_lib, monkeypatch):
+    """The full game runs a specialised encoder (constant section offsets, assembled in
+    registers); the generic one is what the oracle lock-step covers on the small configurations,
+    including the shifted encoding when information tokens exceed their maximum (sim.cpp:676-678).
+    Same states, same actions -> identical tensors, also with token counts 9..13 injected."""
+    n = 3000
+    fast = make(FULL, n)
+    monkeypatch.setenv("MRL_HANABI_VARIANT", "0")
+    slow = make(FULL, n)
+    monkeypatch.delenv("MRL_HANABI_VARIANT")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+
+    def tensors(sim):
+        return [sim.observation_tensor().to_torch(), sim.agent_state_tensor().to_torch(), sim.action_mask_tensor().to_torch(),
+                sim.active_agent_tensor().to_torch(), sim.reward_tensor().to_torch(), sim.done_tensor().to_torch(),
+                sim.game_tensor().to_torch()]
+
+    def same(tag):
+        for k, (a, b) in enumerate(zip(tensors(fast), tensors(slow))):
+            assert torch.equal(a, b), f"tensor {k} differs {tag}"
+
+    same("initially")
+    mask = fast.action_mask_tensor().to_torch()
+    for t in range(120):
+        a = (torch.rand(mask.shape, device="cuda", generator=gen) * mask).argmax(-1, keepdim=True).to(torch.int32)
+        fast.action_tensor().to_torch().copy_(a)
+        slow.action_tensor().to_torch().copy_(a)
+        fast.step()
+        slow.step()
+        same(f"after step {t}")
+        if t % 10 == 5:  # push a third of the worlds over the token maximum (byte 81 of the record = information tokens)
+            extra = torch.randint(8, 14, (n,), device="cuda", generator=gen, dtype=torch.int32).to(torch.uint8)
+            pick = torch.rand(n, device="cuda", generator=gen) < 0.33
+            for sim in (fast, slow):
+                rec = sim.game_tensor().to_torch()
+                rec[:, 81] = torch.where(pick, extra, rec[:, 81])
+    fast.close()
+    slow.close()
