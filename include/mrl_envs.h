@@ -173,7 +173,8 @@ enum {
     MRL_HANABI_AGENT_ID = 7,
     MRL_HANABI_STATE = 8,
     MRL_HANABI_GAME = 9,
-    MRL_HANABI_RESET_COUNT = 10
+    MRL_HANABI_RESET_COUNT = 10,
+    MRL_HANABI_SCAN_TIMEOUT = 11 /* uint32 (1): see mrl_step */
 };
 
 int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
@@ -192,7 +193,8 @@ enum {
     MRL_CARTPOLE_STATE = 2,
     MRL_CARTPOLE_REWARD = 3,
     MRL_CARTPOLE_WORLD_ID = 4,
-    MRL_CARTPOLE_RESET_COUNT = 5
+    MRL_CARTPOLE_RESET_COUNT = 5,
+    MRL_CARTPOLE_SCAN_TIMEOUT = 6 /* uint32 (1): see mrl_step */
 };
 
 int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
@@ -201,7 +203,13 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 /* Common                                                               */
 /* ------------------------------------------------------------------ */
 
-/* One environment step for every world: replaces Manager::step. */
+/* One environment step for every world: replaces Manager::step.
+ * Hanabi and Cartpole number new episodes in ascending world order, which takes a
+ * prefix sum over the worlds that finished.  mrl_step does it inside ONE launch:
+ * each workgroup publishes its count and waits for the lower-numbered workgroups
+ * (csrc/episode_scan.hpp explains why that wait cannot deadlock).  The wait is
+ * bounded all the same; if it ever expired the SCAN_TIMEOUT tensor of the game
+ * becomes nonzero and the episode numbers of that step are unspecified. */
 int mrl_step(mrl_sim *sim, void *hip_stream);
 
 /* Same step, but actions are read from caller memory instead of the ACTION
@@ -219,7 +227,7 @@ int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_st
  * episode_base_dev is a device pointer to one uint32 (the caller computes it
  * from the gathered RESET_COUNTs of the lower ranks without a host sync);
  * NULL means "use and advance the simulator's own counter" (single GPU).
- * mrl_step == phase 1 + phase 2(NULL).  Overcooked has no episode counter:
+ * mrl_step gives the same results as phase 1 + phase 2(NULL).  Overcooked has no episode counter:
  * phase 1 is the whole step and phase 2 is a no-op. */
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream);
 int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_stream);

@@ -99,19 +99,13 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out)
 int mrl_step(mrl_sim *sim, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;
-    return guarded([&] {
-        sim->phase1(nullptr, (hipStream_t)hip_stream);
-        sim->phase2(nullptr, (hipStream_t)hip_stream);
-    });
+    return guarded([&] { sim->step(nullptr, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;
-    return guarded([&] {
-        sim->phase1(actions_dev, (hipStream_t)hip_stream);
-        sim->phase2(nullptr, (hipStream_t)hip_stream);
-    });
+    return guarded([&] { sim->step(actions_dev, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream)

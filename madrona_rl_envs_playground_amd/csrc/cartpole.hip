@@ -17,6 +17,8 @@
 #include "common.hpp"
 #include "episode_scan.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -194,6 +196,74 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
     }
 }
 
+// The whole step in one launch (mrl_step / mrl_step_with_actions on one GPU): workgroup b owns
+// worlds [1024 b, 1024 b + 1024), four per thread, all in registers from the first load to the
+// last store.  Finished worlds get their episode index from the single-launch prefix protocol
+// of episode_scan.hpp and are written once, already re-seeded; the two-launch pair above stays
+// for the sharded path, whose episode base comes from the other ranks between the phases.
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *__restrict__ action,
+                                                                  float4 *__restrict__ state, float *__restrict__ reward,
+                                                                  int32_t *__restrict__ done, unsigned long long *status,
+                                                                  uint32_t epoch, const uint32_t *__restrict__ episode_base,
+                                                                  uint32_t *__restrict__ next_counter,
+                                                                  uint32_t *__restrict__ reset_count, uint32_t *timed_out)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_red[2 * kBlock / 64];
+    const uint32_t first = blockIdx.x * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    float4 s[kUnroll];
+    int32_t a[kUnroll];
+    const uint32_t base = *episode_base;
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        const uint32_t i = first + u * kBlock + threadIdx.x;
+        const uint32_t ic = i < last ? i : first;  // clamped: loads stay in bounds
+        s[u] = state[ic];
+        a[u] = action[ic];
+    }
+    bool over[kUnroll];
+    uint32_t finished = 0;
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        const uint32_t i = first + u * kBlock + threadIdx.x;
+        over[u] = i < last && advance(s[u], a[u]);
+        finished += over[u] ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
+    __syncthreads();
+    uint32_t block_total = 0;
+    for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
+    if (threadIdx.x == 0) mrl::publish_count(status, blockIdx.x, epoch, block_total);
+    __syncthreads();  // s_wave is reused below
+    // everything that does not need the prefix goes out while the other workgroups publish
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        const uint32_t i = first + u * kBlock + threadIdx.x;
+        if (i < last) {
+            if (!over[u]) state[i] = s[u];
+            reward[i] = 1.f;
+            done[i] = over[u] ? 1 : 0;
+        }
+    }
+    if (block_total == 0 && !last_block) return;  // uniform per workgroup
+    uint32_t grand_total = 0;
+    uint32_t running = mrl::wait_prefix(status, gridDim.x, blockIdx.x, epoch, s_red, last_block, &grand_total, timed_out);
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {  // ascending world order: round u covers worlds first + 256 u ...
+        uint32_t total;
+        const uint32_t rank = block_rank(over[u], s_wave, total);
+        if (over[u]) state[first + u * kBlock + threadIdx.x] = fresh_state(base + running + rank);
+        running += total;
+        __syncthreads();
+    }
+    if (last_block && threadIdx.x == 0) {
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
+    }
+}
+
 __global__ void mrl_cartpole_init(uint32_t n, uint32_t world_offset, float4 *state, int32_t *world_id)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,6 +283,24 @@ struct CartpoleSim final : mrl_sim {
     uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
     uint32_t *reset_count = nullptr;
     uint32_t parity = 0;
+    // single-launch step (see mrl_cartpole_step_fused)
+    unsigned long long *status = nullptr;
+    uint32_t *timed_out = nullptr;
+    uint32_t fused_grid = 0, epoch = 0;
+
+    void step(const int32_t *actions, hipStream_t stream) override
+    {
+        if (fused_grid == 0) {
+            mrl_sim::step(actions, stream);
+            return;
+        }
+        epoch += 1;
+        hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds,
+                           actions ? actions : action, state, reward, done, status, epoch, counter + parity,
+                           counter + (parity ^ 1u), reset_count, timed_out);
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
 
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
@@ -256,6 +344,7 @@ struct CartpoleSim final : mrl_sim {
         case MRL_CARTPOLE_REWARD: *out = mrl::make_desc(reward, MRL_FLOAT32, device, {N, 1}); return true;
         case MRL_CARTPOLE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {N, 1}); return true;
         case MRL_CARTPOLE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        case MRL_CARTPOLE_SCAN_TIMEOUT: *out = mrl::make_desc(timed_out, MRL_UINT32, device, {1}); return true;
         default: return false;
         }
     }
@@ -292,6 +381,14 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        {
+            const uint32_t blocks = (num_worlds + kUnroll * kBlock - 1) / (kUnroll * kBlock);
+            if (blocks <= mrl::kMaxFusedBlocks && !getenv("MRL_TWO_LAUNCH_STEP")) {
+                sim->fused_grid = blocks;
+                sim->status = sim->arena.alloc<unsigned long long>(blocks);
+            }
+        }
+        sim->timed_out = sim->arena.alloc<uint32_t>(1);
         sim->reseed_shard(0, num_worlds, 0);
         MRL_HIP(hipDeviceSynchronize());
     } catch (...) {

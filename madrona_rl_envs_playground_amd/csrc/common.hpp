@@ -88,6 +88,12 @@ struct mrl_sim {
     // actions == nullptr -> read the simulator's own ACTION tensor
     virtual void phase1(const int32_t *actions, hipStream_t stream) = 0;
     virtual void phase2(const uint32_t *episode_base_dev, hipStream_t stream) = 0;
+    // whole step; games whose step is two launches may override it with a single fused launch
+    virtual void step(const int32_t *actions, hipStream_t stream)
+    {
+        phase1(actions, stream);
+        phase2(nullptr, stream);
+    }
     // num_steps, seed, first_step: the uniform random policy on the device (include/mrl_envs.h)
     virtual void rollout_random(uint32_t, uint64_t, uint32_t, hipStream_t) { throw std::runtime_error("this game has no device-side random-policy rollout"); }
     virtual void set_episode_counter(uint32_t, hipStream_t) {}

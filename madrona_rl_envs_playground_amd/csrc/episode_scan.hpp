@@ -21,6 +21,14 @@ namespace mrl {
 
 constexpr uint32_t kMaxScanBlocks = 1024;  // 4 workgroups per CU on MI355X
 
+// Workgroup barrier for hand-offs through LDS only.  __syncthreads() also waits for the wave's
+// outstanding global stores (vmcnt(0)) -- microseconds when a wave has just streamed its output
+// rows with write-through stores, and needed by none of the hand-offs in these kernels.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // whole workgroup (blockDim.x a multiple of 64, <= 1024): exclusive prefix of workgroup `block`;
 // with want_total also the sum over all workgroups.  s_red: 2 * blockDim.x / 64 words of LDS.
 __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, uint32_t num_blocks, uint32_t block,
@@ -43,15 +51,106 @@ __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, ui
         s_red[tid >> 6] = before;
         s_red[nwaves + (tid >> 6)] = all;
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t prefix = 0, total = 0;
     for (uint32_t w = 0; w < nwaves; w++) {
         prefix += s_red[w];
         total += s_red[nwaves + w];
     }
-    __syncthreads();
+    lds_barrier();
     if (grand_total) *grand_total = total;
     return prefix;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-launch variant.  Instead of ending the kernel between "count" and "prefix", every
+// workgroup publishes (epoch, count) in one 64-bit word and then waits until all lower-numbered
+// workgroups have published theirs for the same epoch (the host passes a fresh epoch per launch,
+// so the status words are never cleared).  A workgroup only ever waits for LOWER indices and
+// publishes before it waits, and workgroups are dispatched in index order on every XCD, so the
+// lowest unfinished workgroup never waits: the wait cannot deadlock whatever the occupancy.  As a
+// second line of defence the wait is bounded; on expiry *timed_out is set (the launch then
+// finishes with wrong episode numbers instead of hanging the GPU) and the host reports it.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxFusedBlocks = 4096;
+constexpr uint32_t kMaxPolls = 1u << 22;  // ~1 s of polling
+
+__device__ __forceinline__ void publish_count(unsigned long long *status, uint32_t block, uint32_t epoch, uint32_t count)
+{
+    __hip_atomic_store(&status[block], ((unsigned long long)epoch << 32) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// whole workgroup; same contract as scan_prefix
+__device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
+                                                uint32_t *s_red, bool want_total, uint32_t *grand_total, uint32_t *timed_out)
+{
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    uint32_t before = 0, all = 0;
+    const uint32_t limit = want_total ? num_blocks : block;
+    for (uint32_t i = tid; i < limit; i += nthreads) {
+        unsigned long long v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+            if (polls == kMaxPolls) {
+                *timed_out = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t c = (uint32_t)v;
+        before += i < block ? c : 0u;
+        all += c;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_down(before, off, 64);
+        all += __shfl_down(all, off, 64);
+    }
+    const uint32_t nwaves = nthreads >> 6;
+    if ((tid & 63u) == 0) {
+        s_red[tid >> 6] = before;
+        s_red[nwaves + (tid >> 6)] = all;
+    }
+    lds_barrier();
+    uint32_t prefix = 0, total = 0;
+    for (uint32_t w = 0; w < nwaves; w++) {
+        prefix += s_red[w];
+        total += s_red[nwaves + w];
+    }
+    lds_barrier();
+    if (grand_total) *grand_total = total;
+    return prefix;
+}
+
+// One wave's version of wait_prefix (no workgroup barrier): lets ONE wave of a workgroup do the
+// look-back while the others go on.  A vector load cannot return before the wave's older stores
+// have been acknowledged (loads and stores share vmcnt, in issue order), so the wave that looks
+// back should do so before it streams out its own results.
+__device__ __forceinline__ uint32_t wave_wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
+                                                     bool want_total, uint32_t *grand_total, uint32_t *timed_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t before = 0, all = 0;
+    const uint32_t limit = want_total ? num_blocks : block;
+    for (uint32_t i = lane; i < limit; i += 64u) {
+        unsigned long long v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+            if (polls == kMaxPolls) {
+                *timed_out = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t c = (uint32_t)v;
+        before += i < block ? c : 0u;
+        all += c;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off, 64);
+        all += __shfl_xor(all, off, 64);
+    }
+    *grand_total = all;
+    return before;
 }
 
 }  // namespace mrl

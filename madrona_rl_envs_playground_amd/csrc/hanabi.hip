@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -90,8 +91,10 @@ struct HanabiParams {
     const int32_t *actions;  // 2 x N
     uint32_t *block_counts;
     uint32_t chunk;  // worlds per workgroup (multiple of kWorldsPerBlock)
+    uint32_t deck_words[13];  // a fresh game's record bytes 0..51: the ordered deck (sim.cpp:453-468), its size, discard[0]
 #ifdef MRL_DIAG
     unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps (first sub-block)
+    uint32_t ablate;             // diagnostic build only: 1 = skip action + encode, 2 = skip the row stores
 #endif
 };
 
@@ -106,9 +109,11 @@ struct HanabiParams {
         if (p.stamps && lane == 0 && sub == blockIdx.x * p.chunk)                                                 \
             p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
     } while (0)
+#define ABLATED(bit) (p.ablate & (bit))
 #else
 #define STAMP(k) ((void)0)
 #define STAMP_REALTIME(k) ((void)0)
+#define ABLATED(bit) false
 #endif
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -573,20 +578,17 @@ __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
     rec[R_LM_NEWLY] = (uint8_t)newly;
 }
 
-// sim.cpp:446-532, without the encode
+// sim.cpp:446-532, without the encode.  The ten opening draws keep the generator and the deck
+// size in registers; the LDS reads of one draw (the drawn card, the deck's last card) do not
+// depend on the previous draw's write being waited for (DS ops execute in order).
 template <int kR>
 __device__ void deal_new_game(const HanabiParams &p, uint8_t *rec, uint32_t episode)
 {
-    const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks;
-    for (int w = 0; w < kRecordWords; w++) reinterpret_cast<uint32_t *>(rec)[w] = 0;
-    rng_of(rec) = seed_of(episode);
-    uint32_t k = 0;
-    for (uint32_t c = 0; c < K; c++)
-        for (uint32_t r = 0; r < R; r++) {
-            const uint32_t copies = 2u + (r == 0 ? 1u : 0u) - (r == R - 1 ? 1u : 0u);
-            for (uint32_t i = 0; i < copies; i++) rec[R_DECK + k++] = (uint8_t)(R * c + r);
-        }
-    rec[R_DECK_SIZE] = (uint8_t)k;
+    uint32_t *rec32 = reinterpret_cast<uint32_t *>(rec);
+#pragma unroll
+    for (int w = 0; w < 13; w++) rec32[w] = p.deck_words[w];
+#pragma unroll
+    for (int w = 13; w < kRecordWords; w++) rec32[w] = 0;
     rec[R_INFO] = (uint8_t)p.max_info;
     rec[R_LIFE] = (uint8_t)p.max_life;
     rec[R_CUR] = 0;
@@ -598,16 +600,29 @@ __device__ void deal_new_game(const HanabiParams &p, uint8_t *rec, uint32_t epis
     rec[R_LM_COLOR] = 0xFF;
     rec[R_LM_RANK] = 0xFF;
     rec[R_LM_DEALTO] = 0xFF;
+    uint32_t g = seed_of(episode);
+    uint32_t size = p.deck_words[12] >> 16 & 0xFFu;  // byte 50
+    const uint32_t all = ones(p.bpc);
     for (uint32_t a = 0; a < 2; a++) {
         uint8_t *h = rec + R_HAND + HAND_BYTES * a;
+#pragma unroll
         for (uint32_t j = 0; j < kHand; j++) {
-            h[H_CARDS + j] = (uint8_t)draw(rec);
-            plaus_of(h)[j] = ones(p.bpc);
+            // drawDeck (sim.cpp:45-52): one float multiply, truncation
+            g = 1664525u * g + 1013904223u;
+            const float r = (float)(g & 0x00FFFFFFu) / (float)0x01000000;
+            const int32_t at = (int32_t)((float)size * r);
+            const uint8_t card = rec[R_DECK + at];
+            rec[R_DECK + at] = rec[R_DECK + size - 1];
+            size -= 1;
+            h[H_CARDS + j] = card;
+            plaus_of(h)[j] = all;
             h[H_KCOLOR + j] = 0xFF;
             h[H_KRANK + j] = 0xFF;
         }
         h[H_SIZE] = kHand;
     }
+    rec[R_DECK_SIZE] = (uint8_t)size;
+    rng_of(rec) = g;
 }
 
 // 16-byte write-through (sc1) stores: the observation / state / mask rows are written once per
@@ -715,14 +730,21 @@ __device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLd
 
 // Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), p.chunk a
 // multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
-// four waves per SIMD: 65536 worlds = 4096 waves are then resident in one go (at 132 VGPRs, what
-// the compiler picks unasked, a quarter of the workgroups start only when the first ones finish)
-template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) mrl_hanabi_step(const HanabiParams p)
+// The transition of the workgroup's worlds; returns how many of them finished (to every thread).
+// Rows of finished worlds are not written: the reset that follows writes both agents' rows anew.
+// what the single-launch step needs on top of the transition (see mrl_hanabi_step_fused)
+struct FusedScan {
+    unsigned long long *status;
+    uint32_t epoch;
+    uint32_t *s_part;  // LDS: [0] finished worlds before this workgroup, [1] on the whole GPU
+    uint32_t *timed_out;
+};
+
+template <int kV, bool kFused>
+__device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, bool *last_over,
+                                              const FusedScan &scan)
 {
     constexpr int kR = kV ? 5 : 0;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
-    __shared__ uint32_t s_counts[kWavesPerBlock];
     const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
@@ -751,12 +773,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
             const uint32_t actor = rec[R_CUR] & 1u;
-            apply_action<kR>(p, rec, (uint32_t)(actor ? act1 : act0));
+            if (!ABLATED(1)) apply_action<kR>(p, rec, (uint32_t)(actor ? act1 : act0));
             STAMP(2);
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
             // observationSystem (:794-810): only the player to move is refreshed
-            encode_variant<kV>(p, rec, enc, next);
+            if (!ABLATED(1)) encode_variant<kV>(p, rec, enc, next);
             STAMP(3);
             p.active[(size_t)next * N + world] = 1;
             p.active[(size_t)(next ^ 1u) * N + world] = 0;
@@ -773,97 +795,116 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))
             over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
             p.done[world] = over ? 1 : 0;
         }
-        finished += (uint32_t)__popcll(__ballot(over));
+        const unsigned long long overs = __ballot(over);
+        finished += (uint32_t)__popcll(overs);
+        *last_over = over;
         const unsigned long long movers = __ballot(next_is_1);
         wave_lds_sync();
         STAMP(4);
+        if constexpr (kFused) {
+            // The workgroup's count is final once its last sub-block is through phase A: publish
+            // it, and let the last wave look back at the lower workgroups NOW, before its row
+            // stores -- afterwards every load would first sit out the acknowledgement of those
+            // write-through stores (4.6 us measured), and the re-deal below issues no load at all.
+            if (sub + kWorldsPerBlock >= chunk_end) {
+                if (lane == 0) s_counts[wib] = finished;
+                mrl::lds_barrier();
+                if (wib == kWavesPerBlock - 1) {
+                    uint32_t total = 0;
+                    for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
+                    if (lane == 0) mrl::publish_count(scan.status, blockIdx.x, scan.epoch, total);
+                    const bool last_block = blockIdx.x == gridDim.x - 1;
+                    if (total != 0 || last_block) {
+                        uint32_t grand = 0;
+                        const uint32_t before = mrl::wave_wait_prefix(scan.status, gridDim.x, blockIdx.x, scan.epoch, last_block, &grand, scan.timed_out);
+                        if (lane == 0) {
+                            scan.s_part[0] = before;
+                            scan.s_part[1] = grand;
+                        }
+                    }
+                }
+            }
+        }
 
         // phase B: bits -> bytes for every world's player to move; the wave's worlds are one
         // contiguous run of blocks, so a lane's target is a 32-bit offset from a scalar base
         {
             const uint32_t w0s = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0s * kWorldBlock, nw * kWorldBlock);
-            for (uint32_t f = lane; f < nw * kAgentChunks; f += kWave) {
+            for (uint32_t f = lane; f < nw * kAgentChunks && !ABLATED(2); f += kWave) {
                 const uint32_t r = (f * 2731u) >> 18, ch = f - r * kAgentChunks;  // f / 96, exact for f < 6144
                 const uint32_t agent = (uint32_t)(movers >> r) & 1u;
-                row_store(out, r * kWorldBlock + agent * kAgentBlock + ch * 16u, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
+                const uint32_t at = ((overs >> r) & 1ull) ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;  // out of range = dropped
+                row_store(out, at, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
             }
         }
         STAMP(5);
-        for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
+        for (uint32_t r = 0; r < nw; r++)
+            if (!((overs >> r) & 1ull)) store_record(p, l, w0, r, lane);  // a finished world's record comes from the re-deal
         wave_lds_sync();
         STAMP(6);
         STAMP_REALTIME(14);
     }
 
     if (lane == 0) s_counts[wib] = finished;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
-        p.block_counts[blockIdx.x] = total;
-    }
+    mrl::lds_barrier();
+    uint32_t total = 0;
+    for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
+    mrl::lds_barrier();  // s_counts is reused by the reset
+    return total;
 }
 
-// kAll: (re)initialise every world as episode episode_base + world (construction /
-// mrl_reseed_shard); otherwise only the worlds whose done flag is set, numbered in
-// ascending world order from *episode_base.
-template <bool kAll, int kV>
-__global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
-                                                           uint32_t episode_base_value, uint32_t *next_counter,
-                                                           uint32_t *reset_count)
+// four waves per SIMD: 65536 worlds = 4096 waves are then resident in one go (at 132 VGPRs, what
+// the compiler picks unasked, a quarter of the workgroups start only when the first ones finish)
+template <int kV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) mrl_hanabi_step(const HanabiParams p)
 {
-    constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
-    __shared__ uint32_t s_part[2 * kWavesPerBlock];
-    __shared__ uint8_t s_list[kWorldsPerBlock];
+    bool last_over;
+    const uint32_t total = step_body<kV, false>(p, smem, s_counts, &last_over, FusedScan{});
+    if (threadIdx.x == 0) p.block_counts[blockIdx.x] = total;
+}
+
+
+// Re-deal the workgroup's finished worlds (kAll: all of them) as episodes base + running,
+// base + running + 1, ... in ascending world order, and write both agents' rows.
+template <bool kAll, int kV>
+__device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, uint8_t *s_list, uint32_t base,
+                                           uint32_t running, bool have_flag = false, bool flag = false)
+{
+    constexpr int kR = kV ? 5 : 0;
     const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
-    const bool last_block = blockIdx.x == gridDim.x - 1;
     const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
-
-    uint32_t running = 0, grand_total = 0;  // finished worlds before the current sub-block
-    if (!kAll) {
-        if (p.block_counts[blockIdx.x] == 0 && !last_block) return;  // uniform for the workgroup
-        running = mrl::scan_prefix(p.block_counts, gridDim.x, blockIdx.x, s_part, last_block, &grand_total);
-    }
-    const uint32_t base = kAll ? episode_base_value : *episode_base;
-    if (!kAll && last_block && threadIdx.x == 0) {
-        *reset_count = grand_total;
-        *next_counter = base + grand_total;
-    }
-
     // Finished worlds are sparse (a few per 64), so they are compacted over the workgroup first:
-    // s_list holds their local indices in ascending order, wave k re-deals entries
-    // [16k, 16k+16).  Typically only wave 0 has work, instead of every wave running the long
-    // re-deal path for one or two of its lanes.
+    // s_list holds their local indices in ascending order.  Entry e goes to wave e % 4, slot
+    // e / 4, so the long serial re-deal runs on all four SIMDs instead of queueing in wave 0;
+    // the two agents of a re-dealt world are then encoded by two lanes side by side.
     for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {  // uniform trip count
         const uint32_t local = wib * kWorldsPerWave + lane;
-        const bool over = lane < kWorldsPerWave && sub + local < chunk_end && (kAll || p.done[sub + local] != 0);
+        // (the single-launch step hands over the flag it has just computed when the workgroup owns one sub-block)
+        const bool over = lane < kWorldsPerWave && sub + local < chunk_end && (kAll || (have_flag ? flag : p.done[sub + local] != 0));
         const unsigned long long votes = __ballot(over);
         if (lane == 0) s_counts[wib] = (uint32_t)__popcll(votes);
-        __syncthreads();
+        mrl::lds_barrier();
         uint32_t before = 0, total = 0;
         for (uint32_t w = 0; w < kWavesPerBlock; w++) {
             before += w < wib ? s_counts[w] : 0u;
             total += s_counts[w];
         }
         if (over) s_list[before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull))] = (uint8_t)local;
-        __syncthreads();
+        mrl::lds_barrier();
+        STAMP(8);
 
-        const uint32_t my_first = wib * kWorldsPerWave;
-        const uint32_t my_n = total > my_first ? min((uint32_t)kWorldsPerWave, total - my_first) : 0u;
+        const uint32_t my_n = (total + kWavesPerBlock - 1 - wib) / kWavesPerBlock;  // entries wib, wib + 4, ...  (<= 16)
         if (lane < my_n) {
-            const uint32_t entry = my_first + lane;
+            const uint32_t entry = lane * kWavesPerBlock + wib;
             const uint32_t world = sub + s_list[entry];
-            uint8_t *rec = l.rec + lane * kRecStride;
             // entries are in ascending world order, so entry k of this sub-block is the
             // (running + k)-th finished world of the step
-            deal_new_game<kR>(p, rec, base + (kAll ? world : running + entry));
-            encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, 0);
-            encode_variant<kV>(p, rec, l.enc + (lane * 2 + 1) * kEncWords, 1);
+            deal_new_game<kR>(p, l.rec + lane * kRecStride, base + (kAll ? world : running + entry));
             p.active[world] = 1;
             p.active[(size_t)N + world] = 0;
             if (kAll) {
@@ -873,8 +914,12 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
             }
         }
         wave_lds_sync();
+        STAMP(9);
+        if (lane < 2 * my_n) encode_variant<kV>(p, l.rec + (lane >> 1) * kRecStride, l.enc + lane * kEncWords, lane & 1u);
+        wave_lds_sync();
+        STAMP(10);
         for (uint32_t r = 0; r < my_n; r++) {
-            const uint32_t world = sub + s_list[my_first + r];
+            const uint32_t world = sub + s_list[r * kWavesPerBlock + wib];
             const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)world);
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)ws * kWorldBlock, kWorldBlock);
 #pragma unroll
@@ -886,8 +931,67 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
                 p.records[(size_t)world * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
         }
         running += total;
-        __syncthreads();  // s_list / s_counts are rewritten by the next sub-block
+        STAMP(11);
+        STAMP_REALTIME(12);
+        mrl::lds_barrier();  // s_list / s_counts are rewritten by the next sub-block
     }
+}
+
+// kAll: (re)initialise every world as episode episode_base + world (construction /
+// mrl_reseed_shard); otherwise only the worlds whose done flag is set, numbered in
+// ascending world order from *episode_base.
+template <bool kAll, int kV>
+__global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
+                                                           uint32_t episode_base_value, uint32_t *next_counter,
+                                                           uint32_t *reset_count)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_part[2 * kWavesPerBlock];
+    __shared__ uint8_t s_list[kWorldsPerBlock];
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    uint32_t running = 0, grand_total = 0;  // finished worlds before this workgroup's
+    if (!kAll) {
+        if (p.block_counts[blockIdx.x] == 0 && !last_block) return;  // uniform for the workgroup
+        running = mrl::scan_prefix(p.block_counts, gridDim.x, blockIdx.x, s_part, last_block, &grand_total);
+    }
+    const uint32_t base = kAll ? episode_base_value : *episode_base;
+    if (!kAll && last_block && threadIdx.x == 0) {
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
+    }
+    reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running);
+}
+
+// The whole step in one launch (mrl_step on one GPU): transition, then the single-launch prefix
+// protocol of episode_scan.hpp instead of a kernel boundary, then the re-deal.  The two-launch
+// pair stays for the sharded path, whose episode base comes from the other ranks in between.
+template <int kV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
+mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
+                      uint32_t *next_counter, uint32_t *reset_count, uint32_t *timed_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_part[2 * kWavesPerBlock];
+    __shared__ uint8_t s_list[kWorldsPerBlock];
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    const uint32_t base = *episode_base;  // requested now, needed after the transition
+    bool last_over = false;
+    const uint32_t total = step_body<kV, true>(p, smem, s_counts, &last_over, FusedScan{status, epoch, s_part, timed_out});
+    if (total == 0 && !last_block) return;  // uniform for the workgroup
+    const uint32_t running = s_part[0], grand_total = s_part[1];  // left by the last wave (barriers inside step_body)
+    if (last_block && threadIdx.x == 0) {
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
+    }
+    // No global address is written by both parts (the transition skips the rows and the record of
+    // a finished world), so the re-deal needs no ordering against the transition's stores.
+#ifdef MRL_DIAG
+    if (p.stamps && (threadIdx.x & 63) == 0)
+        p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 7] = __builtin_amdgcn_s_memtime();
+#endif
+    reset_body<false, kV>(p, smem, s_counts, s_list, base, running, p.chunk == (uint32_t)kWorldsPerBlock, last_over);
 }
 
 __global__ void fill_agent_ids(int32_t *world_id, int32_t *agent_id, uint32_t n)
@@ -906,6 +1010,31 @@ struct HanabiSim final : mrl_sim {
     uint32_t *counter = nullptr, *reset_count = nullptr;
     uint32_t parity = 0;
     int variant = 0;  // code variant of the kernels (see encode_variant)
+    // single-launch step (mrl_hanabi_step_fused)
+    unsigned long long *status = nullptr;
+    uint32_t *timed_out = nullptr;
+    uint32_t epoch = 0;
+    bool fused = false;
+
+    void step(const int32_t *actions, hipStream_t stream) override
+    {
+        if (!fused) {
+            mrl_sim::step(actions, stream);
+            return;
+        }
+        HanabiParams a = params;
+        a.actions = actions ? actions : action;
+        epoch += 1;
+        const uint32_t *base = counter + parity;
+        uint32_t *next = counter + (parity ^ 1u);
+        switch (variant) {
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
+        }
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
 
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
@@ -980,6 +1109,7 @@ struct HanabiSim final : mrl_sim {
             return true;
         case MRL_HANABI_GAME: *out = mrl::make_desc(params.records, MRL_UINT8, device, {N, kRecordBytes}); return true;
         case MRL_HANABI_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        case MRL_HANABI_SCAN_TIMEOUT: *out = mrl::make_desc(timed_out, MRL_UINT32, device, {1}); return true;
 #ifdef MRL_DIAG
         case 14:
             if (!params.stamps) return false;
@@ -1062,11 +1192,23 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         }
         a.records = sim->arena.alloc<uint32_t>((size_t)N * kRecordWords);
         a.rows = sim->arena.alloc<uint8_t>((size_t)N * kWorldBlock);
+        {
+            uint8_t fresh[52] = {0};
+            uint32_t k = 0;
+            for (uint32_t c = 0; c < K; c++)
+                for (uint32_t r = 0; r < R; r++) {
+                    const uint32_t copies = 2u + (r == 0 ? 1u : 0u) - (r == R - 1 ? 1u : 0u);  // 3, 2.., 1
+                    for (uint32_t i = 0; i < copies; i++) fresh[R_DECK + k++] = (uint8_t)(R * c + r);
+                }
+            fresh[R_DECK_SIZE] = (uint8_t)k;
+            memcpy(a.deck_words, fresh, sizeof(fresh));
+        }
         a.active = sim->arena.alloc<int32_t>((size_t)2 * N);
         a.reward = sim->arena.alloc<float>((size_t)2 * N);
         a.done = sim->arena.alloc<int32_t>(N);
         a.block_counts = sim->arena.alloc<uint32_t>(sim->grid);
 #ifdef MRL_DIAG
+        a.ablate = getenv("MRL_ABLATE") ? (uint32_t)atoi(getenv("MRL_ABLATE")) : 0u;
         a.stamps = getenv("MRL_STAMPS") ? sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16) : nullptr;
 #endif
         sim->action = sim->arena.alloc<int32_t>((size_t)2 * N);
@@ -1074,6 +1216,9 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->agent_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        sim->timed_out = sim->arena.alloc<uint32_t>(1);
+        sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
+        sim->fused = !getenv("MRL_TWO_LAUNCH_STEP");
         hipLaunchKernelGGL(fill_agent_ids, dim3((2 * N + 255) / 256), dim3(256), 0, 0, sim->world_id, sim->agent_id, N);
         MRL_HIP(hipGetLastError());
         sim->reseed_shard(0, N, 0);

@@ -255,6 +255,7 @@ class HanabiSimulator(_Simulator):
     def agent_state_tensor(self): return self._tensor(8)
     def game_tensor(self): return self._tensor(9)
     def reset_count_tensor(self): return self._tensor(10)
+    def scan_timeout_tensor(self): return self._tensor(11)
 
 
 class CartpoleSimulator(_Simulator):
@@ -271,3 +272,4 @@ class CartpoleSimulator(_Simulator):
     def reward_tensor(self): return self._tensor(3)
     def world_id_tensor(self): return self._tensor(4)
     def reset_count_tensor(self): return self._tensor(5)
+    def scan_timeout_tensor(self): return self._tensor(6)

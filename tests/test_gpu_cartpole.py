@@ -75,17 +75,22 @@ def test_lockstep_vs_oracle(n, steps, hip_lib, oracle_lib):
     assert resets > 0
 
 
-def test_two_phase_equals_single_call(hip_lib):
-    n = 5000
+@pytest.mark.parametrize("n,steps", [(5000, 120), (300001, 60), (1 << 20, 25)])
+def test_two_phase_equals_single_call(n, steps, hip_lib):
+    """mrl_step is one fused launch (workgroups wait for each other's counts inside the kernel);
+    the two-phase calls are two launches with the prefix between them.  Same numbers either way."""
     s1, s2 = make(n), make(n)
     torch.manual_seed(1)
-    for _ in range(120):
+    for _ in range(steps):
         a = torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda")
         s1.action_tensor().to_torch().copy_(a)
         s1.step()
         s2.step_phase1(a)
         s2.step_phase2(None)
         assert torch.equal(s1.observation_tensor().to_torch(), s2.observation_tensor().to_torch())
+        assert torch.equal(s1.reset_tensor().to_torch(), s2.reset_tensor().to_torch())
+        assert torch.equal(s1.reset_count_tensor().to_torch(), s2.reset_count_tensor().to_torch())
+    assert int(s1.scan_timeout_tensor().to_torch().item()) == 0
     s1.close()
     s2.close()
 

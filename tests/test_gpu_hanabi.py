@@ -137,3 +137,28 @@ def test_full_game_encoder_matches_generic_encoder(hip_lib, monkeypatch):
                 rec[:, 81] = torch.where(pick, extra, rec[:, 81])
     fast.close()
     slow.close()
+
+
+@pytest.mark.parametrize("cfg,n,steps", [(FULL, 5000, 80), (FULL, 70001, 40), (SMALL, 3000, 60)], ids=["full", "full_70001", "small"])
+def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
+    """mrl_step is one fused launch (workgroups exchange their finished counts inside the
+    kernel); the two-phase calls are two launches.  Same tensors either way."""
+    s1, s2 = make(cfg, n), make(cfg, n)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    mask = s1.action_mask_tensor().to_torch()
+    names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor",
+             "done_tensor", "game_tensor", "reset_count_tensor"]
+    total = 0
+    for t in range(steps):
+        a = (torch.rand(mask.shape, device="cuda", generator=gen) * mask).argmax(-1, keepdim=True).to(torch.int32)
+        s1.action_tensor().to_torch().copy_(a)
+        s1.step()
+        s2.step_phase1(a)
+        s2.step_phase2(None)
+        for name in names:
+            assert torch.equal(getattr(s1, name)().to_torch(), getattr(s2, name)().to_torch()), f"{name} differs at step {t}"
+        total += int(s1.reset_count_tensor().to_torch().item())
+    assert total > 0
+    assert int(s1.scan_timeout_tensor().to_torch().item()) == 0
+    s1.close()
+    s2.close()

@@ -20,6 +20,15 @@ print("s_memtime deltas per wave (cycles; /2400 = us), median [p10..p90] over", 
 for a in range(6):
     d = st[:, a + 1] - st[:, a]
     print(f"{names[a]:>14s} -> {names[a+1]:14s} {np.median(d):8.0f}  [{np.percentile(d,10):7.0f} .. {np.percentile(d,90):7.0f}]  {np.median(d)/2400:5.2f} us")
+full = st[(st[:, 7] > 0) & (st[:, 11] > 0)]
+rnames = {6: "records stored", 7: "prefix known", 8: "compacted", 9: "dealt", 10: "encoded", 11: "rows written"}
+print(f"re-deal part of the fused launch ({len(full)} waves of workgroups with finished worlds)")
+for a, b in zip([6, 7, 8, 9, 10], [7, 8, 9, 10, 11]):
+    d = full[:, b] - full[:, a]
+    print(f"{rnames[a]:>14s} -> {rnames[b]:14s} {np.median(d):8.0f}  [{np.percentile(d,10):7.0f} .. {np.percentile(d,90):7.0f}]  {np.median(d)/2400:5.2f} us")
+if len(full):
+    r12 = full[:, 12] / 100.0
+    print(f"re-deal ends (us after the first start): p50 {np.median(r12 - st[:, 13].min() / 100.0):.2f} max {(r12 - st[:, 13].min() / 100.0).max():.2f}")
 d = st[:, 6] - st[:, 0]
 print(f"sub-block median {np.median(d):.0f} cycles = {np.median(d)/2400:.2f} us, max {d.max()/2400:.2f} us")
 rs, re = st[:, 13] / 100.0, st[:, 14] / 100.0   # s_memrealtime: 100 MHz, common to the whole chip
