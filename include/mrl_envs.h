@@ -243,15 +243,24 @@ int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_strea
  * after construction.  No-op for Overcooked (its initial state is not seeded). */
 int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_total, void *hip_stream);
 
-/* Random-policy rollout on the device (Overcooked only so far):
- * num_steps environment steps in one call, actions drawn in the kernel instead of by
- * torch.randint + copy as in the reference harness (scripts/overcooked_example.py:99-106).
- * The action of (world w, player q) at step index k = first_step, first_step+1, ... is
+/* The random policies of the reference's benchmark harnesses, drawn on the device
+ * (SURVEY.md section 8f item 1): num_steps environment steps with no action tensor to fill.
+ *   Overcooked  randint(high=6) per agent            scripts/overcooked_example.py:99-106
+ *   Cartpole    randint(high=2)                      scripts/cartpole_example.py:53-87
+ *   Hanabi      argmax(rand * mask), i.e. a uniformly random legal move of the player
+ *               to move                              scripts/hanabi_example.py:53-82
+ * All draws come from one counter-based hash of (seed, step index k = first_step,
+ * first_step+1, ..., world w, player q), so a stream can be replayed through mrl_step:
  *     h = lo32(seed) ^ k*0x9E3779B9 ^ w*0x85EBCA6B ^ (q+1)*0xC2B2AE35 ^ hi32(seed)*0x27D4EB2F
  *     h ^= h>>16; h *= 0x7FEB352D; h ^= h>>15; h *= 0x846CA68B; h ^= h>>16;   (all mod 2^32)
- *     action = (h * 6) >> 32
- * so a stream can be replayed through mrl_step.  Every step writes observation, reward and
- * done exactly like mrl_step; after the call the ACTION tensor holds the last step's actions. */
+ *   Overcooked  action = (h * 6) >> 32
+ *   Cartpole    action = h >> 31                      (q = 0)
+ *   Hanabi      action = position of the j-th set bit of the mover's 20-bit legal-move
+ *               mask, j = (h * popcount(mask)) >> 32  (q = the mover)
+ * Every step writes its outputs exactly like mrl_step; afterwards the ACTION tensor holds
+ * the last step's draws (Hanabi: the mover's entry).  Overcooked layouts whose observation
+ * slab fits the LDS tile run all num_steps in ONE launch with the worlds' state resident
+ * in LDS; otherwise, and for the other games, it is one launch per step. */
 int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream);
 
 int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out);

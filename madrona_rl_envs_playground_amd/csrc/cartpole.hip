@@ -16,6 +16,7 @@
 // HBM traffic per world-step: action 4 + state r/w 32 + reward 4 + done 4 = 44 B.
 #include "common.hpp"
 #include "episode_scan.hpp"
+#include "random_policy.hpp"
 
 #include <cstdlib>
 
@@ -206,8 +207,10 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
                                                                   int32_t *__restrict__ done, unsigned long long *status,
                                                                   uint32_t epoch, const uint32_t *__restrict__ episode_base,
                                                                   uint32_t *__restrict__ next_counter,
-                                                                  uint32_t *__restrict__ reset_count, uint32_t *timed_out)
+                                                                  uint32_t *__restrict__ reset_count, uint32_t *timed_out,
+                                                                  int32_t *action_out, uint64_t sample_seed, uint32_t sample_step)
 {
+    // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
     const uint32_t first = blockIdx.x * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
@@ -220,7 +223,12 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
         const uint32_t i = first + u * kBlock + threadIdx.x;
         const uint32_t ic = i < last ? i : first;  // clamped: loads stay in bounds
         s[u] = state[ic];
-        a[u] = action[ic];
+        if (action_out) {
+            a[u] = (int32_t)(mrl::policy_hash(sample_seed, sample_step, ic, 0) >> 31);
+            if (i < last) action_out[i] = a[u];
+        } else {
+            a[u] = action[ic];
+        }
     }
     bool over[kUnroll];
     uint32_t finished = 0;
@@ -264,6 +272,13 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     }
 }
 
+// fallback for batches too large for the single-launch step: draw into the ACTION tensor
+__global__ void mrl_cartpole_draw_actions(int32_t *action, uint32_t n, uint64_t seed, uint32_t step)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) action[i] = (int32_t)(mrl::policy_hash(seed, step, i, 0) >> 31);
+}
+
 __global__ void mrl_cartpole_init(uint32_t n, uint32_t world_offset, float4 *state, int32_t *world_id)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,12 +309,30 @@ struct CartpoleSim final : mrl_sim {
             mrl_sim::step(actions, stream);
             return;
         }
+        launch_fused(actions ? actions : action, nullptr, 0, 0, stream);
+    }
+
+    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
+    {
         epoch += 1;
-        hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds,
-                           actions ? actions : action, state, reward, done, status, epoch, counter + parity,
-                           counter + (parity ^ 1u), reset_count, timed_out);
+        hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions, state,
+                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, timed_out,
+                           action_out, seed, sample_step);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+
+    void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
+    {
+        for (uint32_t k = 0; k < num_steps; k++) {
+            if (fused_grid) {
+                launch_fused(action, action, seed, first_step + k, stream);
+            } else {
+                hipLaunchKernelGGL(mrl_cartpole_draw_actions, dim3((num_worlds + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                                   action, num_worlds, seed, first_step + k);
+                mrl_sim::step(nullptr, stream);
+            }
+        }
     }
 
     void phase1(const int32_t *actions, hipStream_t stream) override

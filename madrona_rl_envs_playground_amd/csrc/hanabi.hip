@@ -27,6 +27,7 @@
 //   mrl_hanabi_reset: prefix over the counts, re-deal finished worlds, encode both agents
 #include "common.hpp"
 #include "episode_scan.hpp"
+#include "random_policy.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -91,6 +92,10 @@ struct HanabiParams {
     const int32_t *actions;  // 2 x N
     uint32_t *block_counts;
     uint32_t chunk;  // worlds per workgroup (multiple of kWorldsPerBlock)
+    // device-side random policy (mrl_rollout_random): sample != 0 -> the mover's action is drawn in the kernel
+    uint32_t sample, sample_step;
+    uint64_t sample_seed;
+    int32_t *action_out;  // ACTION tensor, receives the drawn action
     uint32_t deck_words[13];  // a fresh game's record bytes 0..51: the ordered deck (sim.cpp:453-468), its size, discard[0]
 #ifdef MRL_DIAG
     unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps (first sub-block)
@@ -489,6 +494,30 @@ __device__ __forceinline__ void take_from_hand(const HanabiParams &p, uint8_t *r
     }
 }
 
+// generateActionMask (sim.cpp:381-444) for `agent`, as 20 bits
+template <int kR>
+__device__ __forceinline__ uint32_t legal_moves(const HanabiParams &p, const uint8_t *rec, uint32_t agent)
+{
+    const uint32_t K = p.colors, R = kR ? (uint32_t)kR : p.ranks;
+    const uint8_t *own = rec + R_HAND + HAND_BYTES * agent;
+    const uint8_t *other = rec + R_HAND + HAND_BYTES * (agent ^ 1u);
+    const uint32_t own_size = own[H_SIZE], info = rec[R_INFO];
+    uint32_t legal = 0;
+    for (uint32_t i = 0; i < kHand; i++) {
+        if (i < own_size && info < p.max_info) legal |= 1u << i;
+        if (i < own_size) legal |= 1u << (kHand + i);
+    }
+    if (info > 0) {
+        for (uint32_t n = 0; n < kHand; n++) {  // all five slots, whatever the hand size (:416-417)
+            const uint32_t card = other[H_CARDS + n];
+            const uint32_t col = card / R, rk = card % R;
+            if (col < K) legal |= 1u << (2 * kHand + col);
+            legal |= 1u << (2 * kHand + K + rk);
+        }
+    }
+    return legal & 0xFFFFFu;
+}
+
 // sim.cpp:596-792
 template <int kR>
 __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
@@ -759,7 +788,7 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
         // both agents' actions are fetched with the record (the actor is only known once the
         // record is in LDS; a dependent global load there costs a full HBM latency in phase A)
         int32_t act0 = 0, act1 = 0;
-        if (lane < nw) {
+        if (lane < nw && !p.sample) {
             act0 = p.actions[w0 + lane];
             act1 = p.actions[(size_t)N + w0 + lane];
         }
@@ -773,7 +802,14 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
             const uint32_t actor = rec[R_CUR] & 1u;
-            if (!ABLATED(1)) apply_action<kR>(p, rec, (uint32_t)(actor ? act1 : act0));
+            uint32_t uid = (uint32_t)(actor ? act1 : act0);
+            if (p.sample) {  // uniform over the mover's legal moves (random_policy.hpp)
+                const uint32_t legal = legal_moves<kR>(p, rec, actor);
+                const uint32_t count = (uint32_t)__popc(legal);
+                uid = count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, actor), count)) : 0u;
+                p.action_out[(size_t)actor * N + world] = (int32_t)uid;
+            }
+            if (!ABLATED(1)) apply_action<kR>(p, rec, uid);
             STAMP(2);
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
@@ -1034,6 +1070,19 @@ struct HanabiSim final : mrl_sim {
         }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+
+    void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
+    {
+        const HanabiParams saved = params;
+        params.sample = 1;
+        params.sample_seed = seed;
+        params.action_out = action;
+        for (uint32_t k = 0; k < num_steps; k++) {
+            params.sample_step = first_step + k;
+            step(nullptr, stream);
+        }
+        params = saved;
     }
 
     void phase1(const int32_t *actions, hipStream_t stream) override

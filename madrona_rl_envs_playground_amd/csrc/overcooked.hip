@@ -40,6 +40,7 @@
 //   reward   [P][N]  i32, done [N] i32
 //   obs      [N][P][C][F] u8, F = 5P+16: one contiguous P*C*F block per world
 #include "common.hpp"
+#include "random_policy.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -817,14 +818,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t mrl_random_action(uint64_t seed, uint32_t step, uint32_t world, uint32_t player)
 {
-    uint32_t h = (uint32_t)seed ^ (step * 0x9E3779B9u) ^ (world * 0x85EBCA6Bu) ^ ((player + 1u) * 0xC2B2AE35u) ^
-                 ((uint32_t)(seed >> 32) * 0x27D4EB2Fu);
-    h ^= h >> 16;
-    h *= 0x7FEB352Du;
-    h ^= h >> 15;
-    h *= 0x846CA68Bu;
-    h ^= h >> 16;
-    return (uint32_t)(((uint64_t)h * 6u) >> 32);  // uniform over the six actions
+    return mrl::scale(mrl::policy_hash(seed, step, world, player), 6u);  // uniform over the six actions
 }
 
 template <int kP>

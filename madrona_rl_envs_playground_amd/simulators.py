@@ -81,9 +81,9 @@ class Tensor:
         return self._torch
 
 
-def random_action(seed, step, world, player):
-    """The device-side random policy's action for (step index, world, player): the counter-based
-    hash documented at ``mrl_rollout_random`` in include/mrl_envs.h.  Accepts numpy arrays."""
+def random_hash(seed, step, world, player):
+    """The counter-based hash behind the device-side random policies (``mrl_rollout_random``;
+    csrc/random_policy.hpp), restated with numpy so a stream can be replayed.  uint32 array."""
     import numpy as np
     m = np.uint64(0xFFFFFFFF)
     seed = int(seed) & (2 ** 64 - 1)
@@ -96,7 +96,31 @@ def random_action(seed, step, world, player):
     h ^= h >> np.uint64(15)
     h = h * np.uint64(0x846CA68B) & m
     h ^= h >> np.uint64(16)
-    return ((h * np.uint64(6)) >> np.uint64(32)).astype(np.int32)
+    return h.astype(np.uint32)
+
+
+def random_action(seed, step, world, player):
+    """Overcooked: ``(hash * 6) >> 32`` for (step index, world, player)."""
+    import numpy as np
+    return ((random_hash(seed, step, world, player).astype(np.uint64) * np.uint64(6)) >> np.uint64(32)).astype(np.int32)
+
+
+def random_cartpole_action(seed, step, world):
+    """Cartpole: the hash's top bit (player 0)."""
+    import numpy as np
+    return (random_hash(seed, step, world, np.zeros_like(np.asarray(world))) >> np.uint32(31)).astype(np.int32)
+
+
+def random_hanabi_action(seed, step, world, mover, legal_mask):
+    """Hanabi: the k-th legal move of the mover, ``k = (hash * count) >> 32``.
+    ``legal_mask``: (n, 20) 0/1 array of the mover's legal moves, ``mover``: (n,) 0/1."""
+    import numpy as np
+    legal_mask = np.asarray(legal_mask) != 0
+    count = legal_mask.sum(-1).astype(np.uint64)
+    k = (random_hash(seed, step, world, mover).astype(np.uint64) * count) >> np.uint64(32)
+    rank = np.cumsum(legal_mask, axis=-1) - 1                      # rank of each legal move among the legal ones
+    pick = legal_mask & (rank == k[:, None].astype(np.int64))
+    return np.where(count > 0, pick.argmax(-1), 0).astype(np.int32)
 
 
 class _Simulator:

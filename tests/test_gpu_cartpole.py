@@ -120,3 +120,27 @@ def test_sharded_episode_numbering(hip_lib):
         assert torch.equal(both, whole.observation_tensor().to_torch())
     for s in (whole, lo, hi):
         s.close()
+
+
+def test_device_random_policy(hip_lib):
+    """mrl_rollout_random == stepping with the documented action stream (the hash's top bit)."""
+    from madrona_rl_envs_playground_amd.simulators import random_cartpole_action
+    n, seed = 70001, 77
+    a, b = make(n), make(n)
+    world = np.arange(n)
+    seen = np.zeros(2, np.int64)
+    for t in range(150):
+        want = random_cartpole_action(seed, 9 + t, world)
+        a.rollout_random(1, seed=seed, first_step=9 + t)
+        assert np.array_equal(a.action_tensor().to_torch().cpu().numpy()[:, 0], want)
+        b.action_tensor().to_torch().copy_(torch.from_numpy(want).cuda().view(n, 1))
+        b.step()
+        assert torch.equal(a.observation_tensor().to_torch(), b.observation_tensor().to_torch())
+        assert torch.equal(a.reset_tensor().to_torch(), b.reset_tensor().to_torch())
+        seen += np.bincount(want, minlength=2)
+    assert abs(seen[0] / seen.sum() - 0.5) < 0.01
+    c = make(n)
+    c.rollout_random(150, seed=seed, first_step=9)
+    assert torch.equal(c.observation_tensor().to_torch(), a.observation_tensor().to_torch())
+    for s in (a, b, c):
+        s.close()

@@ -162,3 +162,36 @@ def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
     assert int(s1.scan_timeout_tensor().to_torch().item()) == 0
     s1.close()
     s2.close()
+
+
+@pytest.mark.parametrize("two_launch", [False, True], ids=["single_launch", "two_launch"])
+def test_device_random_policy(two_launch, hip_lib, oracle_lib, monkeypatch):
+    """mrl_rollout_random == the oracle fed the documented stream (uniform over the mover's legal
+    moves, include/mrl_envs.h): checked step by step, then a multi-step call against a replay."""
+    from madrona_rl_envs_playground_amd.simulators import random_hanabi_action
+    if two_launch:
+        monkeypatch.setenv("MRL_TWO_LAUNCH_STEP", "1")
+    n, seed = 2500, 0xC0FFEE1234
+    sim, orc = make(FULL, n), oracle_lib.HanabiOracle(FULL, n, num_threads=8)
+    twin = make(FULL, n)
+    world = np.arange(n)
+    hist = np.zeros(20, np.int64)
+    for t in range(90):
+        mover = (orc.active[1] != 0).astype(np.int64)            # agent whose turn it is
+        legal = orc.mask[mover, world]                            # (n, 20)
+        want = random_hanabi_action(seed, 500 + t, world, mover, legal)
+        assert (legal[world, want] != 0).all()
+        sim.rollout_random(1, seed=seed, first_step=500 + t)
+        got = sim.action_tensor().to_torch().cpu().numpy()[mover, world, 0]
+        assert np.array_equal(got, want), f"drawn actions differ at step {t}"
+        acts = np.zeros((2, n), np.int32)
+        acts[mover, world] = want
+        orc.step(acts)
+        compare(sim, orc, f"step {t}", FULL)
+        hist += np.bincount(want, minlength=20)
+    assert (hist > 0).all(), "some move kind was never drawn"
+    twin.rollout_random(90, seed=seed, first_step=500)           # one call, 90 steps
+    assert torch.equal(twin.game_tensor().to_torch(), sim.game_tensor().to_torch())
+    assert torch.equal(twin.observation_tensor().to_torch(), sim.observation_tensor().to_torch())
+    sim.close()
+    twin.close()

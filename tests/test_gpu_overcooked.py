@@ -202,11 +202,3 @@ def test_device_random_rollout(layout, horizon, cap, n, chunks, hip_lib, oracle_
     orc.step(acts)
     assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs)
     sim.close()
-
-
-def test_rollout_unsupported_games_fail_loudly(hip_lib):
-    from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, MrlError
-    sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=8)
-    with pytest.raises(MrlError, match="random-policy rollout"):
-        sim.rollout_random(3)
-    sim.close()

@@ -143,3 +143,25 @@ def test_random_action_stream_is_uniform_and_reproducible():
         return (h * 6) >> 32
     for seed, k, w, q in [(0, 0, 0, 0), (7, 3, 49999, 1), (2 ** 64 - 1, 2 ** 32 - 1, 12345, 63)]:
         assert int(random_action(seed, k, np.array([w]), np.array([q]))[0]) == scalar(seed, k, w, q)
+
+
+def test_random_policy_host_restatements():
+    """Cartpole and Hanabi draws as documented in include/mrl_envs.h (mrl_rollout_random)."""
+    from madrona_rl_envs_playground_amd.simulators import random_cartpole_action, random_hanabi_action, random_hash
+    w = np.arange(20000)
+    a = random_cartpole_action(3, 11, w)
+    assert set(np.unique(a)) == {0, 1} and abs(a.mean() - 0.5) < 0.02
+    assert np.array_equal(a, (random_hash(3, 11, w, np.zeros_like(w)) >> 31).astype(np.int32))
+    rng = np.random.default_rng(0)
+    legal = (rng.random((20000, 20)) < 0.4).astype(np.int32)
+    legal[:5] = 0                      # no legal move: action 0 by convention
+    legal[5] = 0
+    legal[5, 19] = 1
+    mover = rng.integers(0, 2, 20000)
+    act = random_hanabi_action(5, 2, w, mover, legal)
+    assert (act[:5] == 0).all() and act[5] == 19
+    ok = legal.sum(-1) > 0
+    assert (legal[w[ok], act[ok]] == 1).all()
+    # uniform over the legal moves: position among the legal ones is uniform
+    rank = (np.cumsum(legal, -1) - 1)[w[ok], act[ok]] / legal.sum(-1)[ok]
+    assert abs(rank.mean() - (0.5 - (0.5 / legal.sum(-1)[ok]).mean())) < 0.02

@@ -50,6 +50,16 @@ def main():
     wall, dev = timed(lambda i: sim.step(), args.steps)
     out["hanabi"].update({"us_per_step_kernels_only": dev * 1e6, "steps_per_s_kernels_only": n / dev,
                           "algorithmic_GBps": sim.bytes_per_world_step * n / dev / 1e9})
+    sim.rollout_random(20, seed=1, first_step=0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    sim.rollout_random(args.steps, seed=1, first_step=20)
+    e1.record()
+    torch.cuda.synchronize()
+    dev = e0.elapsed_time(e1) / args.steps * 1e-3
+    out["hanabi"].update({"us_per_step_device_policy": dev * 1e6, "steps_per_s_device_policy": n / dev,
+                          "algorithmic_GBps_device_policy": sim.bytes_per_world_step * n / dev / 1e9})
     sim.close()
 
     n = args.cartpole_worlds
@@ -58,6 +68,15 @@ def main():
     wall, dev = timed(lambda i: sim.step_with_actions(pool[i % 8]), args.steps)
     out["cartpole"] = {"worlds": n, "us_per_step": dev * 1e6, "steps_per_s": n / dev,
                        "algorithmic_GBps": sim.bytes_per_world_step * n / dev / 1e9}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sim.rollout_random(20, seed=1, first_step=0)
+    torch.cuda.synchronize()
+    e0.record()
+    sim.rollout_random(args.steps, seed=1, first_step=20)
+    e1.record()
+    torch.cuda.synchronize()
+    dev = e0.elapsed_time(e1) / args.steps * 1e-3
+    out["cartpole"].update({"us_per_step_device_policy": dev * 1e6, "steps_per_s_device_policy": n / dev})
     sim.close()
     print(json.dumps(out))
 
