@@ -607,6 +607,11 @@ __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
     rec[R_LM_NEWLY] = (uint8_t)newly;
 }
 
+// (A register-resident, select-only version of apply_action for the full game -- header words and
+// both hands read once, all four move kinds straight-line -- was written and measured: 431
+// instructions and the same 2.8 us per wave as this branchy one, whose per-kind paths are short;
+// with four waves per SIMD the phase is issue-bound either way.  Dropped.)
+
 // sim.cpp:446-532, without the encode.  The ten opening draws keep the generator and the deck
 // size in registers; the LDS reads of one draw (the drawn card, the deck's last card) do not
 // depend on the previous draw's write being waited for (DS ops execute in order).
@@ -774,7 +779,8 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
                                               const FusedScan &scan)
 {
     constexpr int kR = kV ? 5 : 0;
-    const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keeps w0, nw and the row descriptors in SGPRs
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
     const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
@@ -910,7 +916,8 @@ __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem,
                                            uint32_t running, bool have_flag = false, bool flag = false)
 {
     constexpr int kR = kV ? 5 : 0;
-    const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keeps w0, nw and the row descriptors in SGPRs
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
     const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);

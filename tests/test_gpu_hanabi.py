@@ -195,3 +195,32 @@ def test_device_random_policy(two_launch, hip_lib, oracle_lib, monkeypatch):
     assert torch.equal(twin.observation_tensor().to_torch(), sim.observation_tensor().to_torch())
     sim.close()
     twin.close()
+
+
+def test_long_games_reach_the_empty_deck(hip_lib, oracle_lib):
+    """A policy that rarely plays keeps its life tokens, so games run until the deck is empty:
+    the shift-left removal from a hand, short hands and the turn countdown (sim.cpp:567-600) are
+    all exercised, in lock-step with the oracle."""
+    n, steps = 600, 230
+    sim, orc = make(FULL, n), oracle_lib.HanabiOracle(FULL, n, num_threads=8)
+    rng = np.random.default_rng(99)
+    act = sim.action_tensor().to_torch()
+    short_hands = empty_decks = finished = 0
+    for t in range(steps):
+        mask = orc.mask.copy()
+        keep_plays = rng.random((2, n)) < 0.03
+        plays = mask[..., 5:10].copy()
+        mask[..., 5:10] = np.where(keep_plays[..., None], plays, 0)
+        none_left = mask.sum(-1) == 0                      # only plays were legal
+        mask[..., 5:10] = np.where(none_left[..., None], plays, mask[..., 5:10])
+        a = legal_random(rng, mask)
+        orc.step(a)
+        act.copy_(torch.from_numpy(a).cuda().view(2, n, 1))
+        sim.step()
+        compare(sim, orc, f"step {t}", FULL)
+        rec = orc.dump()
+        empty_decks += int((rec[:, 50] == 0).sum())
+        short_hands += int(((rec[:, 105] < 5) | (rec[:, 141] < 5)).sum())
+        finished += int(orc.done.sum())
+    assert empty_decks > 0 and short_hands > 0 and finished > 0
+    sim.close()
