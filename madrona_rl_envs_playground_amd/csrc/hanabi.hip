@@ -40,12 +40,15 @@ constexpr int kWave = 64;
 #define MRL_HANABI_WPB 4
 #endif
 #ifndef MRL_HANABI_WPW
-#define MRL_HANABI_WPW 16
+#define MRL_HANABI_WPW 32
 #endif
 constexpr int kWavesPerBlock = MRL_HANABI_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr int kWorldsPerWave = MRL_HANABI_WPW;
 constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
+#ifndef MRL_HANABI_EU
+#define MRL_HANABI_EU 2
+#endif
 
 constexpr int kHand = 5;
 constexpr int kRecordBytes = 176;
@@ -55,7 +58,7 @@ constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-recor
 constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
 // Output rows in HBM: everything one agent of one world receives from a step is ONE 1536-byte
 // block [state 784 | observation 672 | legal-move mask 80], the two agents of a world back to
-// back.  A wave's 16 worlds are 48 KB of contiguous blocks, written with full 1 KB wave stores
+// back.  A wave's 32 worlds are 96 KB of contiguous blocks, written with full 1 KB wave stores
 // that cover whole 128-byte lines; the exported tensors are strided views into the blocks.
 // (Separate obs / state / mask arrays with 672 / 784 / 80-byte rows were measured first: every
 // row end shares a line with the next row, the 80-byte mask rows most of all -- dropping the
@@ -896,10 +899,14 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
     return total;
 }
 
-// four waves per SIMD: 65536 worlds = 4096 waves are then resident in one go (at 132 VGPRs, what
-// the compiler picks unasked, a quarter of the workgroups start only when the first ones finish)
+// Worlds per wave / waves per SIMD, measured at 65536 worlds under the random policy (us per step):
+// 16 worlds x 4 waves 36.2, 24 x 3 37.3, 32 x 2 34.7, 48 x 2 39.1, 64 x 1 48.3.  Phase A costs a wave
+// the same instructions whether 16 or 32 of its lanes are worlds (the kernel issues ~3 200 VALU
+// instructions per wave, PMC), so fewer, fuller waves win until latency is no longer hidden.
+// (With 16 worlds per wave the kernel must be held to 128 VGPRs: at the 132 the compiler picks
+// unasked, a quarter of the workgroups start only when the first ones finish.)
 template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) mrl_hanabi_step(const HanabiParams p)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU))) mrl_hanabi_step(const HanabiParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
@@ -1010,7 +1017,7 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
 // protocol of episode_scan.hpp instead of a kernel boundary, then the re-deal.  The two-launch
 // pair stays for the sharded path, whose episode base comes from the other ranks in between.
 template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
 mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
                       uint32_t *next_counter, uint32_t *reset_count, uint32_t *timed_out)
 {
