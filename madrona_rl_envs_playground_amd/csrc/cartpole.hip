@@ -10,9 +10,11 @@
 // The reference hands out episode indices from one global atomic in whatever
 // order worlds happen to reset (sim.cpp:51-53).  Here the order is fixed:
 // ascending world index within a step.  That needs a prefix sum over the
-// termination flags, so the step is two launches:
-//   mrl_cartpole_step : dynamics + done flag + per-workgroup reset counts
-//   mrl_cartpole_reset: exclusive prefix over the counts, re-seed finished worlds
+// termination flags:
+//   mrl_step             one launch (mrl_cartpole_step_fused, in-kernel prefix, episode_scan.hpp)
+//   mrl_step_phase1 / 2  two launches for sharded batches:
+//     mrl_cartpole_step : dynamics + done flag + per-workgroup reset counts
+//     mrl_cartpole_reset: exclusive prefix over the counts, re-seed finished worlds
 // HBM traffic per world-step: action 4 + state r/w 32 + reward 4 + done 4 = 44 B.
 #include "common.hpp"
 #include "episode_scan.hpp"
@@ -382,7 +384,7 @@ struct CartpoleSim final : mrl_sim {
         }
     }
 
-    const char *kernel_name() const override { return "mrl_cartpole_step"; }
+    const char *kernel_name() const override { return fused_grid ? "mrl_cartpole_step_fused" : "mrl_cartpole_step"; }
     uint64_t bytes_per_world_step() const override { return 44; }
 };
 

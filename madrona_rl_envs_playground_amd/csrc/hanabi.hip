@@ -17,14 +17,18 @@
 //            moves as a bit mask, with a handful of shifted ORs per section;
 //   phase B  all 64 lanes: expand bits to bytes, 16 bits -> one 16-byte store, so
 //            every row is written with full-width coalesced stores.
-// Rows are padded to 16-byte multiples in HBM (obs 672, state 784) and exported
-// as strided (2, N, 658) / (2, N, 783) views.
+// Everything one agent receives is one 1536-byte block in HBM (state | observation |
+// legal-move mask, see kAgentBlock); the reference-shaped tensors are strided views.
 //
 // Episode indices come from one global counter in the reference
 // (sim.cpp:449-451).  As for Cartpole the order is fixed to ascending world
-// index, which needs a prefix sum over the done flags: step = two launches,
-//   mrl_hanabi_step : action + encode + score/done + per-workgroup done counts
-//   mrl_hanabi_reset: prefix over the counts, re-deal finished worlds, encode both agents
+// index, which needs a prefix sum over the done flags:
+//   mrl_step              one launch, mrl_hanabi_step_fused: transition, in-kernel prefix
+//                         (episode_scan.hpp), re-deal of the finished worlds;
+//   mrl_step_phase1 / 2   two launches (sharded batches: the episode base comes from the
+//                         other ranks in between): mrl_hanabi_step = action + encode +
+//                         score/done + per-workgroup done counts, mrl_hanabi_reset = prefix
+//                         over the counts, re-deal, encode both agents.
 #include "common.hpp"
 #include "episode_scan.hpp"
 #include "random_policy.hpp"
@@ -1183,7 +1187,7 @@ struct HanabiSim final : mrl_sim {
         }
     }
 
-    const char *kernel_name() const override { return "mrl_hanabi_step"; }
+    const char *kernel_name() const override { return fused ? "mrl_hanabi_step_fused" : "mrl_hanabi_step"; }
 
     uint64_t bytes_per_world_step() const override
     {

@@ -1131,7 +1131,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // Per-wave LDS.  If the group's whole observation slab fits a tile of kWholeTileMax bytes
         // the encode is single-pass and needs no per-cell tail buffer; otherwise rows go through
         // a kRowsPerPass-row tile fed from a 16-byte-per-cell tail buffer.
-        constexpr uint32_t kWholeTileMax = 8448;  // 4 workgroups x 4 waves x (tile + state) <= 160 KB per CU
+        uint32_t kWholeTileMax = 8448;  // 4 workgroups x 4 waves x (tile + state) <= 160 KB per CU
+        uint32_t lds_max = 65536;
+        if (const char *env = getenv("MRL_OVERCOOKED_WHOLE_MAX")) kWholeTileMax = (uint32_t)atoi(env);  // experiments
+        if (const char *env = getenv("MRL_OVERCOOKED_LDS_MAX")) lds_max = (uint32_t)atoi(env);
         auto layout = [&](uint32_t wpw) {
             auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
             a.wpw = wpw;
@@ -1166,7 +1169,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             while (cand > 1 && (layout(cand), !a.whole)) cand >>= 1;
             if ((layout(cand), a.whole)) wpw = cand;
         }
-        while (wpw > 1 && (layout(wpw) > 65536 || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
+        while (wpw > 1 && (layout(wpw) > lds_max || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
             wpw >>= 1;
         sim->lds_bytes = layout(wpw);
