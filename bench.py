@@ -98,10 +98,19 @@ def main():
     from madrona_rl_envs_playground_amd import layouts
     from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
 
+    # Rehearsal on a one-GPU box (never the measured configuration): MRL_BENCH_REHEARSE=1 puts every rank
+    # on device 0 and runs the rank protocol over gloo, so the multi-rank control flow can be exercised
+    # where only one card exists.  The driver's real runs use one rank per GPU over RCCL.
+    rehearse = world_size > 1 and os.environ.get("MRL_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     params = layouts.get_base_layout_params(args.layout, args.horizon)
     P, n = params["num_players"], args.worlds
@@ -111,7 +120,7 @@ def main():
     pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(args.pool)]
     obs = sim.observation_world_major_tensor().to_torch()
     gathered = None
-    if args.gather_obs and world_size > 1:
+    if args.gather_obs and world_size > 1 and not rehearse:
         gathered = torch.empty((world_size,) + tuple(obs.shape), dtype=obs.dtype, device=obs.device)
 
     def one_step(i):
@@ -133,7 +142,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
