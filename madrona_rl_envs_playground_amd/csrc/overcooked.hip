@@ -442,6 +442,9 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
                                               uint8_t *s_tile, uint32_t P, uint32_t w0, uint32_t nw, uint32_t lane)
 {
     const uint32_t C = p.C, F = p.F, shift = 5 * P, ncells = nw * C;
+#ifdef MRL_DIAG
+    if (p.ablate & 8u) return;  // diagnostic build: no encode at all
+#endif
     // The group's whole observation slab fits one LDS tile (small layouts): zero it, let
     // each cell-lane drop its 16 bytes into the rows of all P viewers plus the two player
     // bytes of whoever stands there, then stream the slab out.  Three LDS round trips per
@@ -479,6 +482,9 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
         }
     }
     wave_lds_sync();
+#ifdef MRL_DIAG
+    if (p.ablate & 2u) return;  // diagnostic build: encode in LDS, no stores to HBM
+#endif
     const uint32_t head = min((16u - mis) & 15u, nbytes);
     if (lane < head) gobs[lane] = tile[lane];
     const uint32_t body = (nbytes - head) >> 4;
@@ -567,7 +573,6 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         uint32_t cell_reg[kBatch];
         uint2 pl_reg = make_uint2(0, 0);
         uint32_t act_reg[kBatch];
-        if (lane < nw) t_loaded = p.timestep[w0 + lane];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -576,6 +581,9 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         if (lane < nplayers) pl_reg = g_pl[lane];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) act_reg[k] = (lane < nw && (uint32_t)k < P) ? (uint32_t)p.actions[(size_t)k * N + w0 + lane] : 0u;
+        // requested last and unconditionally (clamped index): behind a branch hipcc consumes it on the spot,
+        // `s_waitcnt vmcnt(0)` before the other loads of the group are even issued -- one more HBM latency
+        t_loaded = p.timestep[min(w0 + lane, N - 1u)];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
