@@ -151,6 +151,34 @@ __device__ __forceinline__ void lds_store_tail_a2(uint8_t *ptr, const uint4 &t) 
                  : "memory");
 }
 
+// Both even classes without a branch: every lane issues the same five naturally aligned stores
+// (three dwords at the next 4-byte boundaries, two halfwords at the ends), with data and
+// addresses selected per lane.  In the single-pass encode the class follows the lane's parity,
+// so the branchy version executes both classes in every iteration.
+__device__ __forceinline__ void lds_store_tail_even(uint8_t *ptr, const uint4 &t)  // address % 2 == 0
+{
+    const uint32_t addr = lds_addr(ptr);
+    const bool odd2 = (addr & 2u) != 0;       // address % 4 == 2
+    const uint32_t base4 = addr & ~3u;
+    const uint32_t m1 = __builtin_amdgcn_alignbit(t.y, t.x, 16);
+    const uint32_t m2 = __builtin_amdgcn_alignbit(t.z, t.y, 16);
+    const uint32_t m3 = __builtin_amdgcn_alignbit(t.w, t.z, 16);
+    const uint32_t d1 = odd2 ? m1 : t.y, d2 = odd2 ? m2 : t.z, d3 = odd2 ? m3 : t.w;
+    // halfword A: aligned: t.x low at base4;  shifted: t.x low at base4 + 2
+    // halfword B: aligned: t.x high at base4 + 2;  shifted: t.w high at base4 + 16
+    const uint32_t a_addr = odd2 ? base4 + 2u : base4;
+    const uint32_t b_addr = odd2 ? base4 + 16u : base4 + 2u;
+    const uint32_t b_data = odd2 ? t.w : t.x;
+    asm volatile("ds_write_b32 %0, %1 offset:4\n\t"
+                 "ds_write_b32 %0, %2 offset:8\n\t"
+                 "ds_write_b32 %0, %3 offset:12\n\t"
+                 "ds_write_b16 %4, %5\n\t"
+                 "ds_write_b16_d16_hi %6, %7"
+                 :
+                 : "v"(base4), "v"(d1), "v"(d2), "v"(d3), "v"(a_addr), "v"(t.x), "v"(b_addr), "v"(b_data)
+                 : "memory");
+}
+
 __device__ __forceinline__ void lds_store_tail(uint8_t *ptr, const uint4 &t, uint32_t align_class)
 {
     if (align_class == 0) {
@@ -436,6 +464,16 @@ __device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t
 
 // Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
+__device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset, const uint4 &v)
+{
+    u32x4 r;
+    r.x = v.x;
+    r.y = v.y;
+    r.z = v.z;
+    r.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, 16);  // aux bit 4 = sc1 (write-through)
+}
+
 // Single-pass encode of a group's observation slab (small layouts; see the call site).
 __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
@@ -473,7 +511,7 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
         uint32_t off = __umul24(l, p.block_bytes) + __umul24(c, F);  // row (l, viewer 0, c)
         for (uint32_t v = 0; v < P; v++, off += plane) {
             uint8_t *row = tile + off;
-            lds_store_tail(row + shift, t, p.tail_even ? ((mis + off + shift) & 3u) : 1u);
+            lds_store_tail_even(row + shift, t);  // this path is only taken for even P: every tail is 2-byte aligned
             if (occupied) {
                 const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
                 row[rel] = 1;
@@ -489,15 +527,17 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     if (lane < head) gobs[lane] = tile[lane];
     const uint32_t body = (nbytes - head) >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
-    uint4 *dst = reinterpret_cast<uint4 *>(gobs + head);
+    // 16-byte body as raw buffer stores over exactly the body: chunks past its end are dropped by the
+    // bounds check, so the four-deep batches need no per-lane branches
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs + head, 0, (int)(body << 4), 0x00020000);
     for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
         const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
-        const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
-        const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
-        if (ba) stream_store(dst + ka, va);
-        if (bb) stream_store(dst + kb, vb);
-        if (bc) stream_store(dst + kc, vc);
-        if (bd) stream_store(dst + kd, vd);
+        const uint32_t last = body - 1u;
+        const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+        stream_store_rsrc(out, ka << 4, va);
+        stream_store_rsrc(out, kb << 4, vb);
+        stream_store_rsrc(out, kc << 4, vc);
+        stream_store_rsrc(out, kd << 4, vd);
     }
     const uint32_t done_bytes = head + (body << 4);
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
@@ -604,16 +644,20 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     }
     if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
     __syncthreads();
+    // Every lane takes delivery of its timestep here.  Left to its first use (inside `lane < nw`), the
+    // load stays "pending" on the other path in hipcc's bookkeeping and each later reuse of its
+    // register gets an `s_waitcnt vmcnt(0)` -- which by then waits for the wave's stores.
+    asm volatile("" : "+v"(t_loaded));
     if (nw == 0) return;
     STAMP(1);
 
     // ---------------- step: lane = world ----------------
     // (Letting one wave step all worlds of the workgroup, with the other waves waiting, was
     // tried and is no faster: this phase is ~2 us of dependent per-world logic either way.)
+    int32_t out_reward = 0, out_t = 0, out_done = 0;
     if (lane < nw) {
         uint32_t *obj = s_obj + lane * C;
         uint32_t *pl = s_pl + lane * 2 * P;
-        const uint32_t world = w0 + lane;
         int32_t reward = 0, t = 0;
         bool reset_now = kInit;
         if (!kInit) {
@@ -636,9 +680,9 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
                 pl[2 * q + 1] = kItemNone;
             }
         }
-        for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = reward;
-        p.timestep[world] = t;
-        p.done[world] = kInit ? 0 : (int32_t)reset_now;
+        out_reward = reward;
+        out_t = t;
+        out_done = kInit ? 0 : (int32_t)reset_now;
         s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;  // urgency channel (sim.cpp:79-83)
     }
     STAMP(2);
@@ -649,13 +693,22 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
     wave_lds_sync();
 
-    // ---------------- store: LDS -> HBM slab ----------------
-    {
+    // ---------------- store: LDS -> HBM slab, rewards, flags ----------------
+    // The LAST thing a wave does: issued before the observation stream-out these stores sit in front
+    // of it in the wave's vmcnt order, and hipcc parks the wave on `s_waitcnt vmcnt(0)` -- a store
+    // round trip -- as soon as one of their address registers is reused.  Nothing waits for them here.
+    auto store_state = [&]() {
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
         uint2 *g_pl = p.players + (size_t)w0 * P;
         for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
-    }
+        if (lane < nw) {
+            const uint32_t world = w0 + lane;
+            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = out_reward;
+            p.timestep[world] = out_t;
+            p.done[world] = out_done;
+        }
+    };
 
     STAMP(3);
     // ---------------- observe (sim.cpp:68-167, 642-645) ----------------
@@ -665,6 +718,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
         observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+        store_state();
         STAMP(15);
         STAMP_REALTIME(14);
         return;
@@ -808,6 +862,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         }
         STAMP(5 + min(first_world / max(p.wpp, 1u), 8u));
     }
+    store_state();
     STAMP(15);
     STAMP_REALTIME(14);
 }
@@ -870,6 +925,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     if (nw == 0) return;
 
     for (uint32_t k = 0; k < num_steps; k++) {
+        int32_t step_reward = 0, step_done = 0;
         if (lane < nw) {
             uint32_t *obj = s_obj + lane * C;
             uint32_t *pl = s_pl + lane * 2 * P;
@@ -895,8 +951,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
                     pl[2 * q + 1] = kItemNone;
                 }
             }
-            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = reward;
-            p.done[world] = (int32_t)reset_now;
+            step_reward = reward;
+            step_done = (int32_t)reset_now;
             s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
         }
         for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
@@ -905,6 +961,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
             for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
         wave_lds_sync();
         observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+        if (lane < nw) {  // after the stream-out, like the state stores of the single step
+            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + w0 + lane] = step_reward;
+            p.done[w0 + lane] = step_done;
+        }
         wave_lds_sync();
     }
     // state back to HBM once, after the last step
