@@ -94,8 +94,8 @@ __device__ __forceinline__ bool advance(float4 &s, int32_t action)
     float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
     // expression types as written in sim.cpp:70-83
     const float force = (action == 1 ? FORCE_MAG : -FORCE_MAG);
-    const float costheta = cosf(theta);
-    const float sintheta = sinf(theta);
+    float sintheta, costheta;
+    sincosf(theta, &sintheta, &costheta);  // one range reduction for both (sim.cpp:71-72 calls cosf and sinf)
     const float temp = (force + POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / TOTAL_MASS;
     const float thetaacc =
         (GRAVITY * sintheta - costheta * temp) / (LENGTH * (4.0 / 3.0 - MASSPOLE * costheta * costheta / TOTAL_MASS));
