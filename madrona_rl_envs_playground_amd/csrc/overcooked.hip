@@ -572,6 +572,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
 
     STAMP(0);
     STAMP_REALTIME(13);
+    if (ABLATED(16)) return;  // diagnostic build: the empty launch
     // the constant block and the group's state slab are fetched together: one HBM/L2 latency
     const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
@@ -649,6 +650,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // register gets an `s_waitcnt vmcnt(0)` -- which by then waits for the wave's stores.
     asm volatile("" : "+v"(t_loaded));
     if (nw == 0) return;
+    if (ABLATED(32)) return;  // diagnostic build: launch + loads + barrier
     STAMP(1);
 
     // ---------------- step: lane = world ----------------
