@@ -1201,7 +1201,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // Per-wave LDS.  If the group's whole observation slab fits a tile of kWholeTileMax bytes
         // the encode is single-pass and needs no per-cell tail buffer; otherwise rows go through
         // a kRowsPerPass-row tile fed from a 16-byte-per-cell tail buffer.
-        uint32_t kWholeTileMax = 8448;  // 4 workgroups x 4 waves x (tile + state) <= 160 KB per CU
+        // 9400 admits four worlds of a 9x5 layout (asymmetric_advantages: 25.4 -> 21.7 us per launch at 32768
+        // worlds against two worlds per wave); larger tiles were measured and lose (8 worlds of a 5x5 layout:
+        // 15.5 vs 12.4 us, 8 of counter_circuit 20.0 vs 16.7, 16 of cramped_room 12.8 vs 10.8)
+        uint32_t kWholeTileMax = 9400;
         uint32_t lds_max = 65536;
         if (const char *env = getenv("MRL_OVERCOOKED_WHOLE_MAX")) kWholeTileMax = (uint32_t)atoi(env);  // experiments
         if (const char *env = getenv("MRL_OVERCOOKED_LDS_MAX")) lds_max = (uint32_t)atoi(env);
