@@ -477,7 +477,8 @@ __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, u
 // Single-pass encode of a group's observation slab (small layouts; see the call site).
 __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
-                                              uint8_t *s_tile, uint32_t P, uint32_t w0, uint32_t nw, uint32_t lane)
+                                              uint8_t *s_tile, uint32_t P, uint32_t w0, uint32_t nw, uint32_t lane,
+                                              bool prezeroed = false)
 {
     const uint32_t C = p.C, F = p.F, shift = 5 * P, ncells = nw * C;
 #ifdef MRL_DIAG
@@ -491,8 +492,10 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     const uint32_t nbytes = nw * p.block_bytes;
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
     uint8_t *tile = s_tile + mis;
-    const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
-    for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    if (!prezeroed) {
+        const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
+        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    }
     wave_lds_sync();
     const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
     // (Giving a lane the cell pair 2i, 2i+1 so that each store has a wave-uniform alignment
@@ -625,6 +628,11 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         // requested last and unconditionally (clamped index): behind a branch hipcc consumes it on the spot,
         // `s_waitcnt vmcnt(0)` before the other loads of the group are even issued -- one more HBM latency
         t_loaded = p.timestep[min(w0 + lane, N - 1u)];
+        // while the loads are in flight: zero the observation tile of the single-pass encode
+        if (p.whole) {
+            const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;  // covers any start misalignment
+            for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -719,7 +727,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
-        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, !kInit);
         store_state();
         STAMP(15);
         STAMP_REALTIME(14);
