@@ -1050,6 +1050,201 @@ mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t
     reset_body<false, kV>(p, smem, s_counts, s_list, base, running, p.chunk == (uint32_t)kWorldsPerBlock, last_over);
 }
 
+// ---------------------------------------------------------------------------------------------
+// mrl_rollout_random in ONE launch: num_steps steps of the
+// masked-random policy with the game records resident in LDS.  Every step still writes the
+// mover's rows, rewards, dones and the ACTION tensor, and episodes are numbered exactly as by
+// the one-launch-per-step path, which takes two grid-wide hand-offs per step:
+//   * finished counts of the LOWER workgroups in this step (waited for, as in the single step);
+//   * finished counts of ALL workgroups in the previous step (published a whole step earlier),
+//     so that every workgroup knows the step's first episode index without a counter in HBM.
+// Counts travel through a ring of four status arrays tagged with the step's epoch; a workgroup
+// can run at most one step ahead of the slowest one (it needs everybody's previous-step count),
+// so a slot is never overwritten while somebody still reads it.  Unlike the single step this
+// kernel NEEDS all its workgroups resident at once (nobody exits before the last step): the host
+// launches it only if the whole grid fits the GPU and otherwise falls back to one launch per
+// step.  Waits are bounded as everywhere (SCAN_TIMEOUT).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRing = 4;
+
+template <int kV>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
+mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoch0, uint32_t num_steps, uint32_t first_step,
+                   const uint32_t *episode_base, uint32_t *next_counter, uint32_t *reset_count, uint32_t *timed_out)
+{
+    constexpr int kR = kV ? 5 : 0;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_part[4];
+    __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WaveLds l = wave_lds(smem, wib);
+    const uint32_t N = p.num_worlds, G = gridDim.x, b = blockIdx.x;
+    const uint32_t w0 = b * kWorldsPerBlock + wib * kWorldsPerWave;
+    const uint32_t nw = w0 < N ? min((uint32_t)kWorldsPerWave, N - w0) : 0u;
+    const bool last_block = b == G - 1;
+    uint32_t base = *episode_base;  // first episode index of the current step
+    uint32_t last_total = 0;
+
+    load_records(p, l, w0, nw, lane);
+    wave_lds_sync();
+
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const uint32_t epoch = epoch0 + k;
+        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+        const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
+
+        // ---- phase A: draw, act, encode the next mover ----
+        bool over = false, next_is_1 = false;
+        if (lane < nw) {
+            uint8_t *rec = l.rec + lane * kRecStride;
+            const uint32_t world = w0 + lane;
+            const uint32_t actor = rec[R_CUR] & 1u;
+            const uint32_t legal = legal_moves<kR>(p, rec, actor);
+            const uint32_t count = (uint32_t)__popc(legal);
+            const uint32_t uid =
+                count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, first_step + k, world, actor), count)) : 0u;
+            p.action_out[(size_t)actor * N + world] = (int32_t)uid;
+            apply_action<kR>(p, rec, uid);
+            const uint32_t next = rec[R_CUR] & 1u;
+            next_is_1 = next != 0;
+            encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, next);
+            p.active[(size_t)next * N + world] = 1;
+            p.active[(size_t)(next ^ 1u) * N + world] = 0;
+            const int32_t old_score = (int8_t)rec[R_SCORE];
+            int32_t score = 0;
+            if (rec[R_LIFE] > 0)
+                for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
+            rec[R_SCORE] = (uint8_t)score;
+            rec[R_NEWREW] = (uint8_t)(score - old_score);
+            const float rew = (float)(int8_t)(score - old_score);
+            p.reward[world] = rew;
+            p.reward[(size_t)N + world] = rew;
+            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
+            p.done[world] = over ? 1 : 0;
+        }
+        const unsigned long long overs = __ballot(over);
+        const unsigned long long movers = __ballot(next_is_1);
+        const uint32_t mine = (uint32_t)__popcll(overs);
+        if (over) s_fin[wib][__popcll(overs & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        if (lane == 0) s_counts[wib] = mine;
+        mrl::lds_barrier();
+        uint32_t in_block_before = 0, block_total = 0;
+        for (uint32_t w = 0; w < kWavesPerBlock; w++) {
+            in_block_before += w < wib ? s_counts[w] : 0u;
+            block_total += s_counts[w];
+        }
+        // ---- the grid-wide hand-offs, by the last wave, before its own row stores ----
+        if (wib == kWavesPerBlock - 1) {
+            if (lane == 0) mrl::publish_count(now, b, epoch, block_total);
+            uint32_t lower = 0, prev_all = 0;
+            for (uint32_t i = lane; i < G; i += kWave) {
+                if (k > 0) {  // everybody's count of the previous step (published long ago)
+                    unsigned long long v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch - 1u; polls++) {
+                        if (polls == mrl::kMaxPolls) {
+                            *timed_out = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    prev_all += (uint32_t)v;
+                }
+                if (i < b && block_total != 0) {  // the lower workgroups' counts of this step
+                    unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+                        if (polls == mrl::kMaxPolls) {
+                            *timed_out = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    lower += (uint32_t)v;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                lower += __shfl_xor(lower, off, 64);
+                prev_all += __shfl_xor(prev_all, off, 64);
+            }
+            if (lane == 0) {
+                s_part[0] = lower;
+                s_part[1] = prev_all;
+            }
+        }
+
+        // ---- phase B: the movers' rows of the worlds that go on ----
+        {
+            const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
+            for (uint32_t f = lane; f < nw * kAgentChunks; f += kWave) {
+                const uint32_t r = (f * 2731u) >> 18, ch = f - r * kAgentChunks;
+                const uint32_t agent = (uint32_t)(movers >> r) & 1u;
+                const uint32_t at = ((overs >> r) & 1ull) ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;
+                row_store(out, at, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
+            }
+        }
+        mrl::lds_barrier();  // s_part is there; s_counts / s_fin have been read by everybody
+        const uint32_t lower = s_part[0];
+        base += s_part[1];  // previous step's finished worlds, all workgroups (0 in the first step)
+        last_total = s_part[1];
+
+        // ---- re-deal this wave's finished worlds in place ----
+        if (mine != 0) {
+            if (over) {
+                const uint32_t rank = (uint32_t)__popcll(overs & ((1ull << lane) - 1ull));
+                deal_new_game<kR>(p, l.rec + lane * kRecStride, base + lower + in_block_before + rank);
+                p.active[w0 + lane] = 1;
+                p.active[(size_t)N + w0 + lane] = 0;
+            }
+            wave_lds_sync();
+            if (lane < 2 * mine) {
+                const uint32_t who = s_fin[wib][lane >> 1];
+                encode_variant<kV>(p, l.rec + who * kRecStride, l.enc + (who * 2 + (lane & 1u)) * kEncWords, lane & 1u);
+            }
+            wave_lds_sync();
+            for (uint32_t j = 0; j < mine; j++) {
+                const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fin[wib][j]);
+                const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)(w0 + who) * kWorldBlock, kWorldBlock);
+#pragma unroll
+                for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {
+                    const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
+                    row_store(out, f * 16u, agent_chunk(p, l.enc + (who * 2 + agent) * kEncWords, f - agent * kAgentChunks));
+                }
+            }
+        }
+        mrl::lds_barrier();  // s_part / s_counts / s_fin are rewritten by the next step
+    }
+
+    for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
+    // the counter after the rollout: the last step's counts of everybody (the last workgroup has the
+    // highest index, so these are "lower" counts plus its own and the usual wait applies)
+    if (last_block && wib == kWavesPerBlock - 1 && num_steps > 0) {
+        const uint32_t epoch = epoch0 + num_steps - 1u;
+        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+        uint32_t all = 0;
+        for (uint32_t i = lane; i < G; i += kWave) {
+            unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+                if (polls == mrl::kMaxPolls) {
+                    *timed_out = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            all += (uint32_t)v;
+        }
+        for (int off = 32; off > 0; off >>= 1) all += __shfl_xor(all, off, 64);
+        if (lane == 0) {
+            *reset_count = all;
+            *next_counter = base + all;
+        }
+    }
+    (void)last_total;
+}
+
 __global__ void fill_agent_ids(int32_t *world_id, int32_t *agent_id, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1092,8 +1287,35 @@ struct HanabiSim final : mrl_sim {
         parity ^= 1u;
     }
 
+    unsigned long long *ring = nullptr;
+    uint32_t ring_epoch = 0;
+    bool persistent_ok = false;  // the whole grid of mrl_hanabi_rollout is resident at once
+
+    template <int kV> bool launch_rollout(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream)
+    {
+        HanabiParams a = params;
+        a.sample = 1;
+        a.sample_seed = seed;
+        a.action_out = action;
+        hipLaunchKernelGGL((mrl_hanabi_rollout<kV>), dim3(grid), dim3(kBlock), 0, stream, a, ring, ring_epoch + 1u, num_steps, first_step,
+                           counter + parity, counter + (parity ^ 1u), reset_count, timed_out);
+        MRL_HIP(hipGetLastError());
+        ring_epoch += num_steps;
+        parity ^= 1u;
+        return true;
+    }
+
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
+        if (num_steps == 0) return;
+        if (persistent_ok) {
+            switch (variant) {
+            case 2: launch_rollout<2>(num_steps, seed, first_step, stream); break;
+            case 1: launch_rollout<1>(num_steps, seed, first_step, stream); break;
+            default: launch_rollout<0>(num_steps, seed, first_step, stream); break;
+            }
+            return;
+        }
         const HanabiParams saved = params;
         params.sample = 1;
         params.sample_seed = seed;
@@ -1288,6 +1510,19 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->timed_out = sim->arena.alloc<uint32_t>(1);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
         sim->fused = !getenv("MRL_TWO_LAUNCH_STEP");
+        {
+            // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each
+            // other: only usable when the grid fits the GPU in one go and each workgroup owns one sub-block
+            int per_cu = 0, cus = 0;
+            const void *fn = sim->variant == 2 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<2>)
+                             : sim->variant == 1 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<1>)
+                                                 : reinterpret_cast<const void *>(&mrl_hanabi_rollout<0>);
+            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0));
+            MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
+            sim->persistent_ok = sim->fused && !getenv("MRL_HANABI_NO_PERSISTENT") && sim->params.chunk == (uint32_t)kWorldsPerBlock &&
+                                 (uint64_t)sim->grid <= (uint64_t)per_cu * (uint64_t)cus;
+            sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->grid);
+        }
         hipLaunchKernelGGL(fill_agent_ids, dim3((2 * N + 255) / 256), dim3(256), 0, 0, sim->world_id, sim->agent_id, N);
         MRL_HIP(hipGetLastError());
         sim->reseed_shard(0, N, 0);

@@ -224,3 +224,32 @@ def test_long_games_reach_the_empty_deck(hip_lib, oracle_lib):
         finished += int(orc.done.sum())
     assert empty_decks > 0 and short_hands > 0 and finished > 0
     sim.close()
+
+
+@pytest.mark.parametrize("cfg,n", [(FULL, 65536), (FULL, 10000 + 37), (SMALL, 4096)], ids=["full_65536", "full_ragged", "small"])
+def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib, monkeypatch):
+    """mrl_rollout_random keeps the records in LDS for all steps of a call (one launch) when the
+    grid fits the GPU; forced back to one launch per step it must leave identical tensors."""
+    one = make(cfg, n)
+    monkeypatch.setenv("MRL_HANABI_NO_PERSISTENT", "1")
+    many = make(cfg, n)
+    monkeypatch.delenv("MRL_HANABI_NO_PERSISTENT")
+    names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor",
+             "done_tensor", "game_tensor", "reset_count_tensor", "action_tensor"]
+    step = 0
+    for chunk in (1, 2, 7, 40, 1, 64):
+        one.rollout_random(chunk, seed=2024, first_step=step)
+        many.rollout_random(chunk, seed=2024, first_step=step)
+        step += chunk
+        for name in names:
+            assert torch.equal(getattr(one, name)().to_torch(), getattr(many, name)().to_torch()), f"{name} differs after {step} steps"
+    # and an ordinary step continues from either
+    mask = one.action_mask_tensor().to_torch()
+    a = (torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True).to(torch.int32)
+    for sim in (one, many):
+        sim.action_tensor().to_torch().copy_(a)
+        sim.step()
+    assert torch.equal(one.game_tensor().to_torch(), many.game_tensor().to_torch())
+    assert int(one.scan_timeout_tensor().to_torch().item()) == 0
+    one.close()
+    many.close()
