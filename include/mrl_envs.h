@@ -259,9 +259,9 @@ int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_to
  *               mask, j = (h * popcount(mask)) >> 32  (q = the mover)
  * Every step writes its outputs exactly like mrl_step; afterwards the ACTION tensor holds
  * the last step's draws (Hanabi: the mover's entry).  Overcooked layouts whose observation
- * slab fits the LDS tile, and Hanabi batches whose workgroups all fit the GPU at once (65536
- * worlds do), run all num_steps in ONE launch with the worlds' state resident in LDS;
- * otherwise, and for Cartpole, it is one launch per step. */
+ * slab fits the LDS tile, and Hanabi / Cartpole batches whose workgroups all fit the GPU at
+ * once (65536 Hanabi worlds, 1 M Cartpole worlds do), run all num_steps in ONE launch with
+ * the worlds' state resident in LDS / registers; otherwise it is one launch per step. */
 int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream);
 
 int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out);

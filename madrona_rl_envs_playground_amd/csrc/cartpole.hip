@@ -274,6 +274,148 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     }
 }
 
+// mrl_rollout_random in ONE launch: the four worlds of a thread stay in registers for all steps;
+// every step still writes state, reward, done and the drawn action.  Episode numbering needs the
+// same two grid-wide hand-offs per step as mrl_hanabi_rollout (hanabi.hip): the lower workgroups'
+// finished counts of this step (waited for) and everybody's counts of the previous step, through
+// a ring of four epoch-tagged status arrays.  All workgroups must be resident at once (checked on
+// the host, else one launch per step); waits are bounded (SCAN_TIMEOUT).
+constexpr int kRing = 4;
+
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float4 *__restrict__ state, float *__restrict__ reward,
+                                                               int32_t *__restrict__ done, int32_t *__restrict__ action_out,
+                                                               unsigned long long *ring, uint32_t epoch0, uint32_t num_steps,
+                                                               uint32_t first_step, uint64_t seed,
+                                                               const uint32_t *__restrict__ episode_base,
+                                                               uint32_t *__restrict__ next_counter,
+                                                               uint32_t *__restrict__ reset_count, uint32_t *timed_out)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_red[2 * kBlock / 64];
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
+    const bool last_block = b == G - 1;
+    float4 s[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        const uint32_t i = first + u * kBlock + threadIdx.x;
+        s[u] = state[i < last ? i : first];
+    }
+    uint32_t base = *episode_base;
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const uint32_t epoch = epoch0 + k;
+        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+        const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
+        bool over[kUnroll];
+        uint32_t finished = 0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t i = first + u * kBlock + threadIdx.x;
+            const int32_t a = (int32_t)(mrl::policy_hash(seed, first_step + k, i < last ? i : first, 0) >> 31);
+            over[u] = i < last && advance(s[u], a);
+            finished += over[u] ? 1u : 0u;
+            if (i < last) {
+                action_out[i] = a;
+                if (!over[u]) state[i] = s[u];
+                reward[i] = 1.f;
+                done[i] = over[u] ? 1 : 0;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
+        mrl::lds_barrier();
+        uint32_t block_total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
+        if (threadIdx.x == 0) mrl::publish_count(now, b, epoch, block_total);
+        mrl::lds_barrier();  // s_wave is reused below
+        // lower workgroups of this step (only if somebody here finished) and everybody's previous step
+        uint32_t lower = 0, prev_all = 0;
+        for (uint32_t i = threadIdx.x; i < G; i += kBlock) {
+            if (k > 0) {
+                unsigned long long v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch - 1u; polls++) {
+                    if (polls == mrl::kMaxPolls) {
+                        *timed_out = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                prev_all += (uint32_t)v;
+            }
+            if (i < b && block_total != 0) {
+                unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+                    if (polls == mrl::kMaxPolls) {
+                        *timed_out = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                lower += (uint32_t)v;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            lower += __shfl_down(lower, off, 64);
+            prev_all += __shfl_down(prev_all, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_red[threadIdx.x >> 6] = lower;
+            s_red[kBlock / 64 + (threadIdx.x >> 6)] = prev_all;
+        }
+        mrl::lds_barrier();
+        lower = 0;
+        prev_all = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) {
+            lower += s_red[w];
+            prev_all += s_red[kBlock / 64 + w];
+        }
+        base += prev_all;  // first episode index of this step
+        uint32_t running = lower;
+        if (block_total != 0) {  // uniform per workgroup
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {  // ascending world order
+                uint32_t total;
+                const uint32_t rank = block_rank(over[u], s_wave, total);
+                if (over[u]) {
+                    s[u] = fresh_state(base + running + rank);
+                    state[first + u * kBlock + threadIdx.x] = s[u];
+                }
+                running += total;
+                mrl::lds_barrier();
+            }
+        }
+        mrl::lds_barrier();  // s_red / s_wave are rewritten by the next step
+    }
+    if (last_block && num_steps > 0) {  // counter after the rollout: everybody's count of the last step
+        const uint32_t epoch = epoch0 + num_steps - 1u;
+        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+        uint32_t all = 0;
+        for (uint32_t i = threadIdx.x; i < G; i += kBlock) {
+            unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
+                if (polls == mrl::kMaxPolls) {
+                    *timed_out = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            all += (uint32_t)v;
+        }
+        for (int off = 32; off > 0; off >>= 1) all += __shfl_down(all, off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = all;
+        mrl::lds_barrier();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < kBlock / 64; w++) total += s_red[w];
+            *reset_count = total;
+            *next_counter = base + total;
+        }
+    }
+}
+
 // fallback for batches too large for the single-launch step: draw into the ACTION tensor
 __global__ void mrl_cartpole_draw_actions(int32_t *action, uint32_t n, uint64_t seed, uint32_t step)
 {
@@ -324,8 +466,22 @@ struct CartpoleSim final : mrl_sim {
         parity ^= 1u;
     }
 
+    unsigned long long *ring = nullptr;
+    uint32_t ring_epoch = 0;
+    bool persistent_ok = false;  // the whole grid of mrl_cartpole_rollout is resident at once
+
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
+        if (num_steps == 0) return;
+        if (persistent_ok) {
+            hipLaunchKernelGGL(mrl_cartpole_rollout, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, state, reward, done, action,
+                               ring, ring_epoch + 1u, num_steps, first_step, seed, counter + parity, counter + (parity ^ 1u),
+                               reset_count, timed_out);
+            MRL_HIP(hipGetLastError());
+            ring_epoch += num_steps;
+            parity ^= 1u;
+            return;
+        }
         for (uint32_t k = 0; k < num_steps; k++) {
             if (fused_grid) {
                 launch_fused(action, action, seed, first_step + k, stream);
@@ -424,6 +580,13 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             }
         }
         sim->timed_out = sim->arena.alloc<uint32_t>(1);
+        if (sim->fused_grid) {
+            int per_cu = 0, cus = 0;
+            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&mrl_cartpole_rollout), kBlock, 0));
+            MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
+            sim->persistent_ok = !getenv("MRL_CARTPOLE_NO_PERSISTENT") && (uint64_t)sim->fused_grid <= (uint64_t)per_cu * (uint64_t)cus;
+            sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->fused_grid);
+        }
         sim->reseed_shard(0, num_worlds, 0);
         MRL_HIP(hipDeviceSynchronize());
     } catch (...) {

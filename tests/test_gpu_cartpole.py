@@ -122,14 +122,16 @@ def test_sharded_episode_numbering(hip_lib):
         s.close()
 
 
-def test_device_random_policy(hip_lib):
-    """mrl_rollout_random == stepping with the documented action stream (the hash's top bit)."""
+@pytest.mark.parametrize("n,steps", [(70001, 150), (1 << 20, 40)])
+def test_device_random_policy(n, steps, hip_lib):
+    """mrl_rollout_random == stepping with the documented action stream (the hash's top bit); one
+    persistent launch for many steps == many launches of one step."""
     from madrona_rl_envs_playground_amd.simulators import random_cartpole_action
-    n, seed = 70001, 77
+    seed = 77
     a, b = make(n), make(n)
     world = np.arange(n)
     seen = np.zeros(2, np.int64)
-    for t in range(150):
+    for t in range(steps):
         want = random_cartpole_action(seed, 9 + t, world)
         a.rollout_random(1, seed=seed, first_step=9 + t)
         assert np.array_equal(a.action_tensor().to_torch().cpu().numpy()[:, 0], want)
@@ -140,7 +142,14 @@ def test_device_random_policy(hip_lib):
         seen += np.bincount(want, minlength=2)
     assert abs(seen[0] / seen.sum() - 0.5) < 0.01
     c = make(n)
-    c.rollout_random(150, seed=seed, first_step=9)
+    c.rollout_random(steps // 3, seed=seed, first_step=9)
+    c.rollout_random(steps - steps // 3, seed=seed, first_step=9 + steps // 3)
     assert torch.equal(c.observation_tensor().to_torch(), a.observation_tensor().to_torch())
-    for s in (a, b, c):
-        s.close()
+    assert torch.equal(c.reset_tensor().to_torch(), a.reset_tensor().to_torch())
+    assert torch.equal(c.reset_count_tensor().to_torch(), a.reset_count_tensor().to_torch())
+    c.step()  # the episode counter after a rollout continues like after single steps
+    a.step()
+    assert torch.equal(c.observation_tensor().to_torch(), a.observation_tensor().to_torch())
+    for sim in (a, b, c):
+        assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
+        sim.close()
