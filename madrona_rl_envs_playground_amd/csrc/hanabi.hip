@@ -1074,8 +1074,8 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
 {
     constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
-    __shared__ uint32_t s_counts[kWavesPerBlock];
-    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_counts2[2][kWavesPerBlock];  // double-buffered by step parity: no barrier at the end of a step
+    __shared__ uint32_t s_part2[2][2];
     __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1092,6 +1092,7 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
 
     for (uint32_t k = 0; k < num_steps; k++) {
         const uint32_t epoch = epoch0 + k;
+        uint32_t *s_counts = s_counts2[k & 1u], *s_part = s_part2[k & 1u];
         unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
         const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
 
@@ -1214,7 +1215,8 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
                 }
             }
         }
-        mrl::lds_barrier();  // s_part / s_counts / s_fin are rewritten by the next step
+        // (no barrier here: the next step uses the other halves of s_counts2 / s_part2, and nobody can be two
+        // steps ahead of a wave that has not passed this step's second barrier)
     }
 
     for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
