@@ -49,7 +49,10 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef MRL_OVERCOOKED_WPB
+#define MRL_OVERCOOKED_WPB 4
+#endif
+constexpr int kWavesPerBlock = MRL_OVERCOOKED_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr int kRowsPerPass = 128;  // observation rows assembled per LDS tile
 
@@ -577,7 +580,10 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     STAMP_REALTIME(13);
     if (ABLATED(16)) return;  // diagnostic build: the empty launch
     // the constant block and the group's state slab are fetched together: one HBM/L2 latency
-    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
+    constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
+    uint32_t const_word[kConstWordsPerThread];
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
     const uint8_t *s_times = smem + kConstTimes;
     const uint8_t *s_values = smem + kConstValues;
@@ -651,7 +657,9 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
             }
         }
     }
-    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++)
+        if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
     __syncthreads();
     // Every lane takes delivery of its timestep here.  Left to its first use (inside `lane < nw`), the
     // load stays "pending" on the other path in hipcc's bookkeeping and each later reuse of its
@@ -902,7 +910,10 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
+    constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
+    uint32_t const_word[kConstWordsPerThread];
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
     const uint8_t *s_times = smem + kConstTimes;
     const uint8_t *s_values = smem + kConstValues;
@@ -930,7 +941,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
         for (uint32_t i = lane; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
     }
-    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++)
+        if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
     __syncthreads();
     if (nw == 0) return;
 
