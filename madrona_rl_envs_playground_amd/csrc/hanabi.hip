@@ -311,7 +311,7 @@ __device__ void encode_agent(const HanabiParams &p, uint8_t *rec, uint32_t *enc,
 // compile-time constant: the record is read from LDS once (44 words, one wait), the 783 bits are
 // assembled in registers with shifts at constant positions, and 27 words go back to LDS.  The
 // generic encoder above issues ~50 read-modify-write puts with runtime offsets and ~56 waits on
-// LDS reads; measured per wave 5.7 us for it against FILL_ME us for this one.
+// LDS reads; measured per wave (16 worlds, four waves per SIMD) 5.7 us for it against 2.0 us for this one.
 //
 // Sections after the information tokens move up by `excess` (see above); they are assembled
 // relative to bit 200 and merged with one funnel shift per word.
