@@ -89,6 +89,8 @@ struct StepParams {
     unsigned long long *stamps;  // diagnostic build only: per-wave s_memtime stamps
 #endif
     uint32_t whole;        // a group's whole observation slab fits one LDS tile: single-pass encode
+    uint32_t share;        // the waves of a workgroup share ONE world (few worlds x very large observations): each
+                           // steps it redundantly, takes every kWavesPerBlock-th pass of its rows; wave 0 stores the state
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
     uint32_t off_pl, off_act, off_cur, off_flags, off_tail, off_tile;  // byte offsets inside a wave's LDS region
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // cache lines of the state arrays and of the observation slab; keep them in one L2).
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
+    const uint32_t w0 = p.share ? logical_block : (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
 
     // per-wave LDS: the group's state in the same dense order as in HBM
@@ -716,6 +718,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // of it in the wave's vmcnt order, and hipcc parks the wave on `s_waitcnt vmcnt(0)` -- a store
     // round trip -- as soon as one of their address registers is reused.  Nothing waits for them here.
     auto store_state = [&]() {
+        if (p.share && wib != 0) return;  // the siblings computed the same state
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
         uint2 *g_pl = p.players + (size_t)w0 * P;
@@ -783,7 +786,8 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
     }
     uint32_t first_world = 0;  // of the current pass (aligned passes only)
-    for (uint32_t r0 = 0; r0 < (ABLATED(8) ? 0u : total_rows); r0 += pass_rows, first_world += p.wpp) {
+    const uint32_t pass_step = p.share ? kWavesPerBlock * pass_rows : pass_rows;
+    for (uint32_t r0 = p.share ? wib * pass_rows : 0u; r0 < (ABLATED(8) ? 0u : total_rows); r0 += pass_step, first_world += p.wpp) {
         const uint32_t nrows = min(pass_rows, total_rows - r0);
         const uint32_t nbytes = nrows * F;
         uint8_t *g = gobs + (size_t)r0 * F;
@@ -1275,7 +1279,13 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
         }
-        const uint32_t waves = (N + wpw - 1) / wpw;
+        // Few worlds of a large layout leave most of the GPU idle at one wave per world: the four waves of a
+        // workgroup then share a world.  Measured on many_player_layout (15x17) at 1000 worlds, us per step
+        // shared / not: 2 players 9.4 / 10.3, 4 players 14.6 / 18.4, 8 players 36.8 / 32.6, 16 players 97 / 85,
+        // 30 players 564 / 521 -- with many players the redundant transition (serial in the player count, one
+        // active lane) costs more than the extra waves bring, so only up to four players.
+        a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= 4 && !getenv("MRL_OVERCOOKED_NO_SHARE")) ? 1u : 0u;
+        const uint32_t waves = a.share ? N * kWavesPerBlock : (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
 

@@ -73,6 +73,9 @@ def test_golden_vectors(path, hip_lib):
     ("multiplayer_schelling", 40, 3, 130, 120),      # odd player count: byte-wise row tails
     ("cramped_room", 30, 1, 77, 100),                # a single player
     ("many_player_layout", 20, 5, 40, 60),
+    ("many_player_layout", 30, 2, 50, 70),           # few worlds of a large layout: four waves share a world
+    ("many_player_layout", 22, 3, 21, 50),           # the same with an odd player count
+    ("many_player_layout", 26, 4, 35, 60),
     ("cramped_room", 400, None, 40000, 12),          # 8 worlds per wave, ragged last group
 ])
 def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
