@@ -329,33 +329,11 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
         if (threadIdx.x == 0) mrl::publish_count(now, b, epoch, block_total);
         mrl::lds_barrier();  // s_wave is reused below
         // lower workgroups of this step (only if somebody here finished) and everybody's previous step
-        uint32_t lower = 0, prev_all = 0;
-        for (uint32_t i = threadIdx.x; i < G; i += kBlock) {
-            if (k > 0) {
-                unsigned long long v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch - 1u; polls++) {
-                    if (polls == mrl::kMaxPolls) {
-                        *timed_out = 1u;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                prev_all += (uint32_t)v;
-            }
-            if (i < b && block_total != 0) {
-                unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-                    if (polls == mrl::kMaxPolls) {
-                        *timed_out = 1u;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                lower += (uint32_t)v;
-            }
-        }
+        uint32_t lower = 0, prev_all = 0, unused = 0;
+        if (k > 0)
+            for (uint32_t f = 0; f < G; f += kBlock * 4u) prev_all += mrl::read_counts<4>(before_step, f, G, epoch - 1u, 0u, &unused, timed_out, threadIdx.x, kBlock);
+        if (block_total != 0)
+            for (uint32_t f = 0; f < b; f += kBlock * 4u) lower += mrl::read_counts<4>(now, f, b, epoch, 0u, &unused, timed_out, threadIdx.x, kBlock);
         for (int off = 32; off > 0; off >>= 1) {
             lower += __shfl_down(lower, off, 64);
             prev_all += __shfl_down(prev_all, off, 64);
@@ -391,19 +369,8 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
     if (last_block && num_steps > 0) {  // counter after the rollout: everybody's count of the last step
         const uint32_t epoch = epoch0 + num_steps - 1u;
         unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
-        uint32_t all = 0;
-        for (uint32_t i = threadIdx.x; i < G; i += kBlock) {
-            unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-                if (polls == mrl::kMaxPolls) {
-                    *timed_out = 1u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            all += (uint32_t)v;
-        }
+        uint32_t all = 0, unused = 0;
+        for (uint32_t f = 0; f < G; f += kBlock * 4u) all += mrl::read_counts<4>(now, f, G, epoch, 0u, &unused, timed_out, threadIdx.x, kBlock);
         for (int off = 32; off > 0; off >>= 1) all += __shfl_down(all, off, 64);
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = all;
         mrl::lds_barrier();

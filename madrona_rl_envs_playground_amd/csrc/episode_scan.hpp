@@ -80,6 +80,40 @@ __device__ __forceinline__ void publish_count(unsigned long long *status, uint32
     __hip_atomic_store(&status[block], ((unsigned long long)epoch << 32) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum of the counts status[first .. first + stride * kBatch) visible to this thread (index first + lane + stride j),
+// waiting for each word's epoch tag.  All loads of the batch are issued before the first tag is looked
+// at: a one-at-a-time loop pays a full memory round trip per status word (8..16 of them per lane).
+template <int kBatch>
+__device__ __forceinline__ uint32_t read_counts(const unsigned long long *status, uint32_t first, uint32_t limit, uint32_t epoch,
+                                                uint32_t below, uint32_t *sum_below, uint32_t *timed_out,
+                                                uint32_t lane = threadIdx.x & 63u, uint32_t stride = 64u)
+{
+    unsigned long long v[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; j++) {
+        const uint32_t i = first + lane + stride * j;
+        v[j] = i < limit ? __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    uint32_t all = 0;
+#pragma unroll
+    for (int j = 0; j < kBatch; j++) {
+        const uint32_t i = first + lane + stride * j;
+        if (i < limit) {
+            for (uint32_t polls = 0; (uint32_t)(v[j] >> 32) != epoch; polls++) {
+                if (polls == kMaxPolls) {
+                    *timed_out = 1u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                v[j] = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            all += (uint32_t)v[j];
+            *sum_below += i < below ? (uint32_t)v[j] : 0u;
+        }
+    }
+    return all;
+}
+
 // whole workgroup; same contract as scan_prefix
 __device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
                                                 uint32_t *s_red, bool want_total, uint32_t *grand_total, uint32_t *timed_out)
@@ -87,20 +121,8 @@ __device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t before = 0, all = 0;
     const uint32_t limit = want_total ? num_blocks : block;
-    for (uint32_t i = tid; i < limit; i += nthreads) {
-        unsigned long long v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-            if (polls == kMaxPolls) {
-                *timed_out = 1u;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const uint32_t c = (uint32_t)v;
-        before += i < block ? c : 0u;
-        all += c;
-    }
+    for (uint32_t first = 0; first < limit; first += nthreads * 4u)
+        all += read_counts<4>(status, first, limit, epoch, block, &before, timed_out, tid, nthreads);
     for (int off = 32; off > 0; off >>= 1) {
         before += __shfl_down(before, off, 64);
         all += __shfl_down(all, off, 64);
@@ -128,23 +150,9 @@ __device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint
 __device__ __forceinline__ uint32_t wave_wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
                                                      bool want_total, uint32_t *grand_total, uint32_t *timed_out)
 {
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t before = 0, all = 0;
     const uint32_t limit = want_total ? num_blocks : block;
-    for (uint32_t i = lane; i < limit; i += 64u) {
-        unsigned long long v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-            if (polls == kMaxPolls) {
-                *timed_out = 1u;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const uint32_t c = (uint32_t)v;
-        before += i < block ? c : 0u;
-        all += c;
-    }
+    for (uint32_t first = 0; first < limit; first += 64u * 8u) all += read_counts<8>(status, first, limit, epoch, block, &before, timed_out);
     for (int off = 32; off > 0; off >>= 1) {
         before += __shfl_xor(before, off, 64);
         all += __shfl_xor(all, off, 64);

@@ -1139,33 +1139,12 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
         // ---- the grid-wide hand-offs, by the last wave, before its own row stores ----
         if (wib == kWavesPerBlock - 1) {
             if (lane == 0) mrl::publish_count(now, b, epoch, block_total);
-            uint32_t lower = 0, prev_all = 0;
-            for (uint32_t i = lane; i < G; i += kWave) {
-                if (k > 0) {  // everybody's count of the previous step (published long ago)
-                    unsigned long long v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch - 1u; polls++) {
-                        if (polls == mrl::kMaxPolls) {
-                            *timed_out = 1u;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                        v = __hip_atomic_load(&before_step[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    prev_all += (uint32_t)v;
-                }
-                if (i < b && block_total != 0) {  // the lower workgroups' counts of this step
-                    unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-                        if (polls == mrl::kMaxPolls) {
-                            *timed_out = 1u;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                        v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    lower += (uint32_t)v;
-                }
-            }
+            uint32_t lower = 0, prev_all = 0, unused = 0;
+            if (k > 0)  // everybody's count of the previous step (published long ago)
+                for (uint32_t first = 0; first < G; first += kWave * 8u)
+                    prev_all += mrl::read_counts<8>(before_step, first, G, epoch - 1u, 0u, &unused, timed_out);
+            if (block_total != 0)  // the lower workgroups' counts of this step
+                for (uint32_t first = 0; first < b; first += kWave * 8u) lower += mrl::read_counts<8>(now, first, b, epoch, 0u, &unused, timed_out);
             for (int off = 32; off > 0; off >>= 1) {
                 lower += __shfl_xor(lower, off, 64);
                 prev_all += __shfl_xor(prev_all, off, 64);
@@ -1225,19 +1204,8 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
     if (last_block && wib == kWavesPerBlock - 1 && num_steps > 0) {
         const uint32_t epoch = epoch0 + num_steps - 1u;
         unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
-        uint32_t all = 0;
-        for (uint32_t i = lane; i < G; i += kWave) {
-            unsigned long long v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t polls = 0; (uint32_t)(v >> 32) != epoch; polls++) {
-                if (polls == mrl::kMaxPolls) {
-                    *timed_out = 1u;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                v = __hip_atomic_load(&now[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            all += (uint32_t)v;
-        }
+        uint32_t all = 0, unused = 0;
+        for (uint32_t first = 0; first < G; first += kWave * 8u) all += mrl::read_counts<8>(now, first, G, epoch, 0u, &unused, timed_out);
         for (int off = 32; off > 0; off >>= 1) all += __shfl_xor(all, off, 64);
         if (lane == 0) {
             *reset_count = all;
