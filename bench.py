@@ -176,6 +176,23 @@ def main():
                  "us_per_step": fused_ms * 1e3 / args.fused_steps,
                  "note": "every step still writes its observation slab, rewards and dones"}
 
+    # extra, never `value`: the SAME workload (the pre-sampled resident action pool, in order) as one open-loop
+    # sequence per launch (mrl_step_sequence): what the per-step launches and the state round trips cost
+    seq = None
+    if world_size == 1 and args.fused_steps > 0:
+        k_seq = min(args.fused_steps, 512)
+        seq_actions = torch.stack([pool[i % args.pool] for i in range(k_seq)]).contiguous()
+        sim.step_sequence(seq_actions)
+        torch.cuda.synchronize()
+        ev0.record()
+        sim.step_sequence(seq_actions)
+        ev1.record()
+        torch.cuda.synchronize()
+        seq_ms = ev0.elapsed_time(ev1)
+        seq = {"value": n * k_seq / (seq_ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": k_seq, "us_per_step": seq_ms * 1e3 / k_seq,
+               "note": "same resident action pool, one launch per sequence; every step still writes observations, rewards, dones"}
+        del seq_actions
+
     if rank == 0:
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
         # inside this process); only reported when they were taken on this exact workload
@@ -211,6 +228,8 @@ def main():
         }
         if fused is not None:
             out["fused_random_rollout"] = fused
+        if seq is not None:
+            out["action_sequence_per_launch"] = seq
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -243,6 +243,13 @@ int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_strea
  * after construction.  No-op for Overcooked (its initial state is not seeded). */
 int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_total, void *hip_stream);
 
+/* num_steps steps driven by an open-loop action array: actions_dev holds num_steps consecutive
+ * ACTION tensors (step k at offset k * elements(ACTION), same dtype and layout, device pointer).
+ * Same results as num_steps calls of mrl_step_with_actions.  Overcooked layouts whose observation
+ * slab fits the LDS tile run them in ONE launch with the worlds' state resident in LDS (every
+ * step still writes its observations, rewards and dones); everything else is one launch per step. */
+int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_steps, void *hip_stream);
+
 /* The random policies of the reference's benchmark harnesses, drawn on the device
  * (SURVEY.md section 8f item 1): num_steps environment steps with no action tensor to fill.
  *   Overcooked  randint(high=6) per agent            scripts/overcooked_example.py:99-106

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mrl_overcooked_create", "mrl_hanabi_create", "mrl_cartpole_create", "mrl_step", "mrl_step_with_actions",
     "mrl_step_phase1", "mrl_step_phase2", "mrl_set_episode_counter", "mrl_reseed_shard", "mrl_tensor", "mrl_game",
     "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
-    "mrl_abi_version", "mrl_rollout_random",
+    "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
     L.mrl_set_episode_counter.argtypes = [vp, u32, vp]
     L.mrl_reseed_shard.argtypes = [vp, u32, u32, vp]
     L.mrl_rollout_random.argtypes = [vp, u32, ctypes.c_uint64, u32, vp]
+    L.mrl_step_sequence.argtypes = [vp, vp, u32, vp]
     L.mrl_tensor.argtypes = [vp, i32, ctypes.POINTER(TensorDesc)]
     L.mrl_game.argtypes = [vp]
     L.mrl_num_worlds.argtypes = [vp]

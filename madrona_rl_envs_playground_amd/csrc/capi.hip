@@ -132,6 +132,16 @@ int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_to
     return guarded([&] { sim->reseed_shard(world_offset, num_worlds_total, (hipStream_t)hip_stream); });
 }
 
+int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_steps, void *hip_stream)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    if (!actions_dev && num_steps) {
+        mrl::set_error("mrl_step_sequence: null action array");
+        return MRL_ERR_INVALID;
+    }
+    return guarded([&] { sim->step_sequence(actions_dev, num_steps, (hipStream_t)hip_stream); });
+}
+
 int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;

@@ -507,6 +507,7 @@ struct CartpoleSim final : mrl_sim {
         }
     }
 
+    size_t action_elems() const override { return (size_t)num_worlds; }
     const char *kernel_name() const override { return fused_grid ? "mrl_cartpole_step_fused" : "mrl_cartpole_step"; }
     uint64_t bytes_per_world_step() const override { return 44; }
 };

@@ -94,6 +94,13 @@ struct mrl_sim {
         phase1(actions, stream);
         phase2(nullptr, stream);
     }
+    // num_steps steps driven by a caller-provided action array of num_steps consecutive ACTION tensors;
+    // default: one launch per step (`action_elems` = elements of one ACTION tensor)
+    virtual size_t action_elems() const = 0;
+    virtual void step_sequence(const int32_t *actions, uint32_t num_steps, hipStream_t stream)
+    {
+        for (uint32_t k = 0; k < num_steps; k++) step(actions + (size_t)k * action_elems(), stream);
+    }
     // num_steps, seed, first_step: the uniform random policy on the device (include/mrl_envs.h)
     virtual void rollout_random(uint32_t, uint64_t, uint32_t, hipStream_t) { throw std::runtime_error("this game has no device-side random-policy rollout"); }
     virtual void set_episode_counter(uint32_t, hipStream_t) {}

@@ -1381,6 +1381,7 @@ struct HanabiSim final : mrl_sim {
         }
     }
 
+    size_t action_elems() const override { return (size_t)2 * num_worlds; }
     const char *kernel_name() const override { return fused ? "mrl_hanabi_step_fused" : "mrl_hanabi_step"; }
 
     uint64_t bytes_per_world_step() const override

@@ -908,7 +908,8 @@ __host__ __device__ __forceinline__ uint32_t mrl_random_action(uint64_t seed, ui
 
 template <int kP>
 __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout(const StepParams p, uint32_t num_steps, uint64_t seed,
-                                                                                 uint32_t first_step, int32_t *action_out)
+                                                                                 uint32_t first_step, int32_t *action_out,
+                                                                                 const int32_t *action_seq)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -951,6 +952,13 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     __syncthreads();
     if (nw == 0) return;
 
+    // mrl_step_sequence with a compile-time player count: the next step's actions are requested before this
+    // step's row assembly, so their latency is not in the step-to-step chain
+    constexpr int kAhead = kP > 0 ? kP : 1;
+    int32_t ahead[kAhead];
+    const bool prefetch = kP > 0 && action_seq != nullptr;
+    if (prefetch && lane < nw)
+        for (int q = 0; q < kAhead; q++) ahead[q] = action_seq[(size_t)q * N + w0 + lane];
     for (uint32_t k = 0; k < num_steps; k++) {
         int32_t step_reward = 0, step_done = 0;
         if (lane < nw) {
@@ -959,9 +967,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
             uint8_t *act = s_act + lane * P;
             const uint32_t world = w0 + lane;
             for (uint32_t q = 0; q < P; q++) {
-                const uint32_t a = mrl_random_action(seed, first_step + k, world, q);
+                uint32_t a;
+                if (action_seq) {  // mrl_step_sequence: step k's actions from the caller's (num_steps, P, N) array
+                    a = prefetch ? (uint32_t)ahead[kP > 0 ? q : 0] : (uint32_t)action_seq[((size_t)k * P + q) * N + world];
+                    a = a <= A_INTERACT ? a : (uint32_t)A_STAY;
+                } else {
+                    a = mrl_random_action(seed, first_step + k, world, q);
+                    if (k + 1 == num_steps) action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
+                }
                 act[q] = (uint8_t)a;
-                if (k + 1 == num_steps) action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
             }
             int32_t reward;
             if constexpr (kP > 0)
@@ -987,6 +1001,8 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         if (lane < nw)
             for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
         wave_lds_sync();
+        if (prefetch && lane < nw && k + 1 < num_steps)
+            for (int q = 0; q < kAhead; q++) ahead[q] = action_seq[((size_t)(k + 1) * P + q) * N + w0 + lane];
         observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         if (lane < nw) {  // after the stream-out, like the state stores of the single step
             for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + w0 + lane] = step_reward;
@@ -1054,10 +1070,10 @@ struct OvercookedSim final : mrl_sim {
         if (params.whole) {
             if (params.P == 2)
                 hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, seed, first_step, action);
+                                   params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
             else
                 hipLaunchKernelGGL((mrl_overcooked_rollout<0>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, seed, first_step, action);
+                                   params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
             MRL_HIP(hipGetLastError());
             return;
         }
@@ -1067,6 +1083,22 @@ struct OvercookedSim final : mrl_sim {
                                action, params.P, num_worlds, seed, first_step + k);
             launch(false, nullptr, stream);
         }
+    }
+
+    void step_sequence(const int32_t *actions, uint32_t num_steps, hipStream_t stream) override
+    {
+        if (num_steps == 0) return;
+        if (params.whole) {
+            if (params.P == 2)
+                hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
+                                   params, num_steps, 0ull, 0u, action, actions);
+            else
+                hipLaunchKernelGGL((mrl_overcooked_rollout<0>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
+                                   params, num_steps, 0ull, 0u, action, actions);
+            MRL_HIP(hipGetLastError());
+            return;
+        }
+        mrl_sim::step_sequence(actions, num_steps, stream);
     }
 
     void ensure_ids()
@@ -1119,6 +1151,7 @@ struct OvercookedSim final : mrl_sim {
         }
     }
 
+    size_t action_elems() const override { return (size_t)params.P * num_worlds; }
     const char *kernel_name() const override { return params.P == 2 ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
 
     uint64_t bytes_per_world_step() const override

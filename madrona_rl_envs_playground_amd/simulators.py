@@ -161,6 +161,16 @@ class _Simulator:
         if rc:
             _lib.check(rc)
 
+    def step_sequence(self, actions):
+        """One step per leading index of ``actions`` (int32, shape (K,) + ACTION tensor's shape, contiguous,
+        on this GPU): same results as K ``step_with_actions`` calls (``mrl_step_sequence``)."""
+        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device.index != self.gpu_id:
+            raise ValueError("actions must be a contiguous int32 tensor on the simulator's device")
+        if actions.dim() < 1 or actions.numel() != actions.shape[0] * self._action_numel:
+            raise ValueError(f"actions must hold K x {self._action_numel} elements, got shape {tuple(actions.shape)}")
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        _lib.check(self._L.mrl_step_sequence(self._handle, actions.data_ptr(), int(actions.shape[0]), stream))
+
     def rollout_random(self, num_steps, seed=0, first_step=0):
         """``num_steps`` steps under the uniform random policy, actions drawn on the
         device (``mrl_rollout_random``; see ``random_action`` for the stream)."""

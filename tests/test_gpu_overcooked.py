@@ -205,3 +205,26 @@ def test_device_random_rollout(layout, horizon, cap, n, chunks, hip_lib, oracle_
     orc.step(acts)
     assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs)
     sim.close()
+
+
+@pytest.mark.parametrize("layout,cap,n,steps", [("cramped_room", None, 5000, 90), ("coordination_ring", None, 777, 70),
+                                                 ("many_player_layout", 8, 33, 25)])
+def test_step_sequence_equals_single_steps(layout, cap, n, steps, hip_lib):
+    """mrl_step_sequence (one launch for the whole action array where the layout allows) leaves the
+    tensors K calls of step_with_actions leave, with the final step's observation, reward and done."""
+    params = layouts.get_base_layout_params(layout, 31, max_num_players=cap)
+    P = params["num_players"]
+    a, b = make_sim(params, n), make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    acts = torch.randint(0, 6, (steps, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+    done_any = 0
+    for lo, hi in ((0, 1), (1, steps // 2), (steps // 2, steps)):
+        a.step_sequence(acts[lo:hi].contiguous())
+        for k in range(lo, hi):
+            b.step_with_actions(acts[k])
+        for name in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_players_tensor",
+                     "state_objects_tensor", "state_timestep_tensor"):
+            assert torch.equal(getattr(a, name)().to_torch(), getattr(b, name)().to_torch()), f"{name} after step {hi}"
+        done_any += int(b.done_tensor().to_torch().sum().item())
+    a.close()
+    b.close()
