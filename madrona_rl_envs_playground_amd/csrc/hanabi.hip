@@ -743,6 +743,62 @@ __device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
     return WaveLds{base, reinterpret_cast<uint32_t *>(base + kWorldsPerWave * kRecStride)};
 }
 
+// Phase B for a wave's movers: the 96 chunks of an agent block times the wave's worlds, 64 chunks per
+// store.  Three stores cover exactly two worlds, so which chunk (state / observation / mask piece, bit
+// range, word of the bit vector) a lane writes in each of the three is fixed for the whole launch and is
+// worked out once; the loop only adds the pair's LDS base, clips, spreads and stores.
+__device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveLds &l, uint32_t nw, unsigned long long overs,
+                                              unsigned long long movers, __amdgpu_buffer_rsrc_t out, uint32_t lane)
+{
+    uint32_t wsel[3], ch16[3], woff[3], sh[3], first[3], base_bits[3], cap[3], mshift[3];
+    bool is_mask[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const uint32_t f = (uint32_t)t * kWave + lane;                       // 0..191 within the pair
+        wsel[t] = f >= (uint32_t)kAgentChunks ? 1u : 0u;
+        const uint32_t ch = f - wsel[t] * kAgentChunks;
+        const bool is_state = ch < (uint32_t)kStateChunks;
+        is_mask[t] = ch >= (uint32_t)(kStateChunks + kObsChunks);
+        const uint32_t k = is_state ? ch : ch - kStateChunks;
+        ch16[t] = ch * 16u;
+        woff[t] = wsel[t] * (2u * kEncWords) + min(k >> 1, 24u);            // word of the pair's bit vectors
+        sh[t] = (k & 1u) * 16u;
+        first[t] = k * 16u;
+        base_bits[t] = is_state ? p.state_bits : p.obs_bits;
+        cap[t] = is_state ? (uint32_t)MRL_HANABI_STATE_SIZE : (uint32_t)MRL_HANABI_OBS_SIZE;
+        mshift[t] = is_mask[t] ? 4u * (ch - (kStateChunks + kObsChunks)) : 0u;
+    }
+    for (uint32_t r0 = 0; r0 < nw; r0 += 2) {
+        const uint32_t *pair = l.enc + r0 * 2 * kEncWords;
+        const uint32_t mv0 = (uint32_t)(movers >> r0) & 1u, mv1 = (uint32_t)(movers >> (r0 + 1u)) & 1u;
+        const bool skip0 = (overs >> r0) & 1ull, skip1 = ((overs >> (r0 + 1u)) & 1ull) || r0 + 1u >= nw;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t *mine = pair + wsel[t] * (2u * kEncWords);
+            const uint32_t word = pair[woff[t]];
+            const uint32_t legal = mine[25], excess = mine[26];
+            // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the shifted
+            // encoding pushes past the row end is dropped (the reference writes it out of bounds)
+            const uint32_t limit = min(base_bits[t] + excess, cap[t]);
+            // (component-wise: a select between two uint4 values makes hipcc park them in scratch memory)
+            const uint32_t piece = clip16((word >> sh[t]) & 0xFFFFu, first[t], limit);
+            uint32_t v0 = spread4(piece), v1 = spread4(piece >> 4), v2 = spread4(piece >> 8), v3 = spread4(piece >> 12);
+            if (t > 0) {  // the first store of a pair holds no mask chunk
+                const uint32_t bits = legal >> mshift[t];
+                v0 = is_mask[t] ? (bits & 1u) : v0;
+                v1 = is_mask[t] ? ((bits >> 1) & 1u) : v1;
+                v2 = is_mask[t] ? ((bits >> 2) & 1u) : v2;
+                v3 = is_mask[t] ? ((bits >> 3) & 1u) : v3;
+            }
+            const uint4 v = make_uint4(v0, v1, v2, v3);
+            const uint32_t agent = wsel[t] ? mv1 : mv0;
+            const bool skip = wsel[t] ? skip1 : skip0;
+            const uint32_t at = skip ? 0xFFFFFFF0u : (r0 + wsel[t]) * kWorldBlock + agent * kAgentBlock + ch16[t];  // out of range = dropped
+            row_store(out, at, v);
+        }
+    }
+}
+
 __device__ __forceinline__ void load_records(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t nw, uint32_t lane)
 {
     // all global loads of the wave's records are in flight before the first LDS write
@@ -882,12 +938,7 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
         {
             const uint32_t w0s = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0s * kWorldBlock, nw * kWorldBlock);
-            for (uint32_t f = lane; f < nw * kAgentChunks && !ABLATED(2); f += kWave) {
-                const uint32_t r = (f * 2731u) >> 18, ch = f - r * kAgentChunks;  // f / 96, exact for f < 6144
-                const uint32_t agent = (uint32_t)(movers >> r) & 1u;
-                const uint32_t at = ((overs >> r) & 1ull) ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;  // out of range = dropped
-                row_store(out, at, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
-            }
+            if (!ABLATED(2)) expand_movers(p, l, nw, overs, movers, out, lane);
         }
         STAMP(5);
         for (uint32_t r = 0; r < nw; r++)
@@ -1158,12 +1209,7 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
         // ---- phase B: the movers' rows of the worlds that go on ----
         {
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
-            for (uint32_t f = lane; f < nw * kAgentChunks; f += kWave) {
-                const uint32_t r = (f * 2731u) >> 18, ch = f - r * kAgentChunks;
-                const uint32_t agent = (uint32_t)(movers >> r) & 1u;
-                const uint32_t at = ((overs >> r) & 1ull) ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;
-                row_store(out, at, agent_chunk(p, l.enc + r * 2 * kEncWords, ch));
-            }
+            expand_movers(p, l, nw, overs, movers, out, lane);
         }
         mrl::lds_barrier();  // s_part is there; s_counts / s_fin have been read by everybody
         const uint32_t lower = s_part[0];
