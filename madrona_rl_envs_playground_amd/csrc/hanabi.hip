@@ -614,10 +614,150 @@ __device__ void apply_action(const HanabiParams &p, uint8_t *rec, uint32_t uid)
     rec[R_LM_NEWLY] = (uint8_t)newly;
 }
 
-// (A register-resident, select-only version of apply_action for the full game -- header words and
-// both hands read once, all four move kinds straight-line -- was written and measured: 431
-// instructions and the same 2.8 us per wave as this branchy one, whose per-kind paths are short;
-// with four waves per SIMD the phase is issue-bound either way.  Dropped.)
+// actionSystem (sim.cpp:596-792) for the full game on registers: the header words and both hands
+// are read from LDS once, every move kind is straight-line selects, and the changed words go back
+// once.  Only the discard pile and the deck are touched in place (indexed by a card value / a random
+// position).  The branchy version above has shorter per-kind paths but ~50 LDS waits.  Measured: no
+// difference at 16 worlds per wave / four waves per SIMD (2.8 us per wave either way), 31.3 against
+// 31.7 us per launch at 32 worlds per wave / two waves per SIMD.
+__device__ void apply_action_full(uint8_t *rec, uint32_t uid)
+{
+    constexpr uint32_t kRk = 5, kAll = (1u << 25) - 1u;
+    uint32_t *rec32 = reinterpret_cast<uint32_t *>(rec);
+    const uint32_t w19 = rec32[19], w20 = rec32[20], w21 = rec32[21];
+    const uint32_t deck_size = rec[R_DECK_SIZE];
+    const uint32_t actor = (w20 >> 24) & 1u;
+    uint32_t *ah = rec32 + (R_HAND + HAND_BYTES * actor) / 4;          // mover's hand
+    uint32_t *ph = rec32 + (R_HAND + HAND_BYTES * (actor ^ 1u)) / 4;   // partner's hand
+    uint32_t a[9], q[9];
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        a[w] = ah[w];
+        q[w] = ph[w];
+    }
+    auto hbyte = [](const uint32_t (&h)[9], uint32_t b) { return (h[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu; };
+
+    uint32_t turns = w21 & 0xFFu;
+    if (deck_size == 0) turns = (turns - 1u) & 0xFFu;
+    uint32_t info = (w20 >> 8) & 0xFFu, life = (w20 >> 16) & 0xFFu;
+    const unsigned long long fw = (unsigned long long)w19 | ((unsigned long long)(w20 & 0xFFu) << 32);
+
+    const bool is_card = uid < 2 * kHand;
+    const bool play = is_card && uid >= kHand;
+    const uint32_t slot = is_card ? (play ? uid - kHand : uid) : 0u;
+
+    // ---- discard / play (:634-691) ----
+    uint32_t card_of[kHand], kc_of[kHand], kk_of[kHand];
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        card_of[i] = hbyte(a, H_CARDS + i);
+        kc_of[i] = hbyte(a, H_KCOLOR + i);
+        kk_of[i] = hbyte(a, H_KRANK + i);
+    }
+    uint32_t chosen = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) chosen = slot == i ? card_of[i] : chosen;
+    const uint32_t card = min(chosen, 24u);
+    const uint32_t col = (card * 205u) >> 10, rk = card - col * kRk;
+    const uint32_t top = (uint32_t)(fw >> (8u * col)) & 0xFFu;
+    const bool success = play && top == rk;
+    const bool completed = success && top + 1u == kRk;
+    if (is_card && !success) rec[R_DISCARD + card]++;   // a discard, or a failed play
+    info += (is_card && !play) ? 1u : 0u;
+    info += completed ? 1u : 0u;
+    life -= (play && !success) ? 1u : 0u;
+    const unsigned long long fw_new = fw + (success ? 1ull << (8u * col) : 0ull);
+
+    // removeFromHand (:567-594): redraw into the slot, or shift left when the deck is empty
+    uint32_t size_a = hbyte(a, H_SIZE);
+    uint32_t pl_of[kHand];
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) pl_of[i] = a[4 + i];
+    if (is_card) {
+        if (deck_size == 0) {
+#pragma unroll
+            for (uint32_t i = 0; i + 1 < kHand; i++) {
+                const bool take_next = i >= slot && i + 1 < size_a;
+                card_of[i] = take_next ? card_of[i + 1] : card_of[i];
+                kc_of[i] = take_next ? kc_of[i + 1] : kc_of[i];
+                kk_of[i] = take_next ? kk_of[i + 1] : kk_of[i];
+                pl_of[i] = take_next ? pl_of[i + 1] : pl_of[i];
+            }
+            size_a = (size_a - 1u) & 0xFFu;
+        } else {
+            const uint32_t drawn = draw(rec);
+#pragma unroll
+            for (uint32_t i = 0; i < kHand; i++) {
+                const bool here = i == slot;
+                card_of[i] = here ? drawn : card_of[i];
+                kc_of[i] = here ? 0xFFu : kc_of[i];
+                kk_of[i] = here ? 0xFFu : kk_of[i];
+                pl_of[i] = here ? kAll : pl_of[i];
+            }
+        }
+    }
+
+    // ---- hints (:695-788) ----
+    const bool hint_move = !is_card;
+    const uint32_t u = uid - 2 * kHand;
+    const bool by_color = u < 5u;
+    const uint32_t u_rank = u - 5u;
+    const uint32_t val = by_color ? u : u_rank - ((u_rank * 205u) >> 10) * kRk;  // (uid - K) % R
+    const uint32_t hint = by_color ? 0x1Fu << (kRk * val) : 0x108421u << val;     // the 5 cards of a colour / of a rank
+    const uint32_t psize = min(hbyte(q, H_SIZE), (uint32_t)kHand);
+    uint32_t reveal = 0, newly = 0;
+    uint32_t qkc[kHand], qkk[kHand], qpl[kHand];
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        const uint32_t c = hbyte(q, H_CARDS + i);
+        const uint32_t ccol = (c * 205u) >> 10, crk = c - ccol * kRk;
+        qkc[i] = hbyte(q, H_KCOLOR + i);
+        qkk[i] = hbyte(q, H_KRANK + i);
+        qpl[i] = q[4 + i];
+        const bool live = hint_move && i < psize;
+        const bool match = live && (by_color ? ccol == val : crk == val);
+        reveal |= match ? 1u << i : 0u;
+        newly |= (match && qkc[i] == 0xFFu) ? 1u << i : 0u;  // sim.cpp:776 tests known_color for rank hints too
+        qpl[i] = live ? (match ? qpl[i] & hint : qpl[i] & ~hint) : qpl[i];
+        qkc[i] = (match && by_color) ? val : qkc[i];
+        qkk[i] = (match && !by_color) ? val : qkk[i];
+    }
+    info -= hint_move ? 1u : 0u;
+
+    // ---- write back ----
+    const uint32_t lm_move = is_card ? (play ? (uint32_t)MV_PLAY : (uint32_t)MV_DISCARD) : (by_color ? (uint32_t)MV_REVEAL_COLOR : (uint32_t)MV_REVEAL_RANK);
+    const uint32_t lm_color = is_card ? col : (by_color ? val : 0xFFu);
+    const uint32_t lm_rank = is_card ? rk : (by_color ? 0xFFu : val);
+    rec32[19] = (uint32_t)fw_new;
+    rec32[20] = (uint32_t)(fw_new >> 32) | ((info & 0xFFu) << 8) | ((life & 0xFFu) << 16) | ((actor ^ 1u) << 24);
+    rec32[21] = turns | (w21 & 0x00FFFF00u) | (lm_move << 24);
+    rec32[22] = actor | ((hint_move ? (actor ^ 1u) : 0xFFu) << 8) | ((is_card ? slot : 0xFFu) << 16) | ((success ? 1u : 0u) << 24);
+    rec32[23] = (completed ? 1u : 0u) | (lm_color << 8) | (lm_rank << 16) | (reveal << 24);
+    rec32[24] = newly | (0xFFu << 8) | (rec32[24] & 0xFFFF0000u);
+    if (is_card) {
+        ah[0] = card_of[0] | (card_of[1] << 8) | (card_of[2] << 16) | (card_of[3] << 24);
+        ah[1] = card_of[4] | (size_a << 8) | (kc_of[0] << 16) | (kc_of[1] << 24);
+        ah[2] = kc_of[2] | (kc_of[3] << 8) | (kc_of[4] << 16) | (kk_of[0] << 24);
+        ah[3] = kk_of[1] | (kk_of[2] << 8) | (kk_of[3] << 16) | (kk_of[4] << 24);
+#pragma unroll
+        for (uint32_t i = 0; i < kHand; i++) ah[4 + i] = pl_of[i];
+    } else {
+        ph[1] = (q[1] & 0x0000FFFFu) | (qkc[0] << 16) | (qkc[1] << 24);
+        ph[2] = qkc[2] | (qkc[3] << 8) | (qkc[4] << 16) | (qkk[0] << 24);
+        ph[3] = qkk[1] | (qkk[2] << 8) | (qkk[3] << 16) | (qkk[4] << 24);
+#pragma unroll
+        for (uint32_t i = 0; i < kHand; i++) ph[4 + i] = qpl[i];
+    }
+}
+
+template <int kV>
+__device__ __forceinline__ void apply_variant(const HanabiParams &p, uint8_t *rec, uint32_t uid)
+{
+    if constexpr (kV == 2)
+        apply_action_full(rec, uid);
+    else
+        apply_action<(kV ? 5 : 0)>(p, rec, uid);
+}
 
 // sim.cpp:446-532, without the encode.  The ten opening draws keep the generator and the deck
 // size in registers; the LDS reads of one draw (the drawn card, the deck's last card) do not
@@ -878,7 +1018,7 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
                 uid = count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, actor), count)) : 0u;
                 p.action_out[(size_t)actor * N + world] = (int32_t)uid;
             }
-            if (!ABLATED(1)) apply_action<kR>(p, rec, uid);
+            if (!ABLATED(1)) apply_variant<kV>(p, rec, uid);
             STAMP(2);
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
@@ -1158,7 +1298,7 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
             const uint32_t uid =
                 count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, first_step + k, world, actor), count)) : 0u;
             p.action_out[(size_t)actor * N + world] = (int32_t)uid;
-            apply_action<kR>(p, rec, uid);
+            apply_variant<kV>(p, rec, uid);
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
             encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, next);
