@@ -3,37 +3,47 @@
 
 Contract (one JSON line on rank 0):
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+For N > 1 without a launcher this process only SPAWNS `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N ... bench.py <same flags>` (before anything touches the GPU) and returns its exit
+code; under a launcher (WORLD_SIZE set) it is one rank of the job.
 
-Workload = BASELINE.json configs[1]: Overcooked cramped_room, 32768 worlds per
-GPU, horizon 400, uniform random actions (scripts/overcooked_example.py:99-116
-of the reference: `randint(high=6)` per agent per step, sampling outside the
-timed call).  A step = one `mrl_step_with_actions` launch over the rank's
-world shard, actions already resident in HBM (a pre-sampled pool, cycled).
-Worlds are independent, so ranks do not communicate inside the timed region
-(weak scaling, 32768 worlds per GPU); `--gather-obs` adds the RCCL all-gather of
-the observation shards for consumers that need the global batch on every rank.
+Workload = BASELINE.json configs[1]: Overcooked cramped_room, 32768 worlds per GPU, horizon 400,
+uniform random actions (scripts/overcooked_example.py:99-116 of the reference: `randint(high=6)` per
+agent per step, sampling outside the timed call).  A step = one `mrl_step_with_actions` launch over
+the rank's world shard, actions already resident in HBM (a pre-sampled pool, cycled).  Worlds are
+independent, so ranks do not communicate inside the timed region of `value` (weak scaling, 32768
+worlds per GPU).  N > 1 also times the `obs_gather` leg of BASELINE.json configs[3]: the same step
+followed by the RCCL all-gather of the world-major observation shards (34 MB per rank per step).
 
-Also reported: `roofline` (achieved algorithmic HBM GB/s of the step kernel,
-timed per launch with HIP events on the launch stream) and `cpu_baseline` (the
-test-only CPU oracle in oracle/, timed on this host's cores on a bounded sample).
+Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barrier +
+`torch.cuda.synchronize()` on both sides, max over ranks.  One block is the contract; when K steps
+are shorter than 50 ms (K = 20 is 0.2 ms here) the block is repeated and the MEDIAN block is
+reported (`timing.blocks` says how many), so that one scheduling hiccup is not the result.
+
+Also on the line: `roofline` (algorithmic HBM bytes of the step kernel / its average launch duration,
+HIP events on the launch stream over >= 300 back-to-back launches; spec and on-box measured peaks),
+`cpu_baseline` (the test-only CPU oracle in oracle/ on this host's cores, bounded sample), and the
+reference harness's own two timed regions, `wrapped_n_step` (scripts/overcooked_example.py:104-106)
+and `isolated_with_copies` (scripts/overcooked_isolated_example.py:56-65).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MIN_BLOCK_SECONDS = 0.05
+MIN_ROOFLINE_LAUNCHES = 300
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -41,12 +51,27 @@ def parse():
     ap.add_argument("--worlds", type=int, default=32768, help="worlds per GPU")
     ap.add_argument("--layout", default="cramped_room")
     ap.add_argument("--horizon", type=int, default=400)
-    ap.add_argument("--gather-obs", action="store_true", help="all-gather observation shards every step (RCCL)")
+    ap.add_argument("--no-gather-leg", action="store_true", help="N > 1: skip the obs all-gather leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: only the headline, roofline and cpu_baseline")
     ap.add_argument("--fused-steps", type=int, default=1000, help="steps of the extra device-side random rollout (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--pool", type=int, default=64, help="pre-sampled action tensors cycled through")
-    return ap.parse_args()
+    ap.add_argument("--large-worlds", type=int, default=1 << 20, help="worlds of the large-batch roofline point (0 = skip)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 and no launcher: start the N ranks as a child job.  Nothing in THIS process has
+    touched the GPU (torch is not even imported), and the child is a child, never an exec."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores():
@@ -66,6 +91,7 @@ def cpu_baseline(params, seconds):
     """TEST-ONLY oracle timed as the CPU baseline (kind 'port'): same layout,
     same action distribution, the host cores available to this job, a bounded
     number of world-steps."""
+    import numpy as np
     from oracle import oracle
     cores = min(host_cores(), 64)
     n = 32768
@@ -84,29 +110,31 @@ def cpu_baseline(params, seconds):
             "sample": f"{steps} steps x {n} worlds of the same workload ({dt:.1f} s, OpenMP over worlds)"}
 
 
-def main():
-    args = parse()
+def run(args):
+    import torch
+    import torch.distributed as dist
+    from madrona_rl_envs_playground_amd import _lib, layouts
+    from madrona_rl_envs_playground_amd.distributed import gather_worlds
+    from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
+
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus and world_size > 1:
+    if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    if args.gpus > 1 and world_size == 1:
-        raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N")
-
-    import torch.distributed as dist
-    from madrona_rl_envs_playground_amd import layouts
-    from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
 
     # Rehearsal on a one-GPU box (never the measured configuration): MRL_BENCH_REHEARSE=1 puts every rank
-    # on device 0 and runs the rank protocol over gloo, so the multi-rank control flow can be exercised
-    # where only one card exists.  The driver's real runs use one rank per GPU over RCCL.
+    # on device 0 and runs the rank protocol over gloo (observation gather staged through the host), so
+    # the multi-rank control flow can be exercised where only one card exists.  The driver's real runs
+    # use one rank per GPU over RCCL.
     rehearse = world_size > 1 and os.environ.get("MRL_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world_size > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -115,83 +143,194 @@ def main():
     params = layouts.get_base_layout_params(args.layout, args.horizon)
     P, n = params["num_players"], args.worlds
     sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, **params)
+    C, F = sim.height * sim.width, 5 * P + 16
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
     pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(args.pool)]
     obs = sim.observation_world_major_tensor().to_torch()
-    gathered = None
-    if args.gather_obs and world_size > 1 and not rehearse:
-        gathered = torch.empty((world_size,) + tuple(obs.shape), dtype=obs.dtype, device=obs.device)
-
-    def one_step(i):
-        sim.step_with_actions(pool[i % args.pool])
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, obs)
 
     def fence():
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world_size > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    def max_over_ranks(x):
+        if world_size == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
-    # average launch duration of the step kernel: HIP events on the launch stream (torch's
-    # current stream is the stream the C ABI is handed) around K back-to-back launches.  The
-    # queue never drains, so elapsed / K is the kernel's duration (rocprofv3 --kernel-trace
-    # agrees within 1%, profiles/); bracketing every launch with its own event pair would add
-    # ~2 us of marker overhead to a ~10 us kernel.
-    k_launch = args.steps
+    def all_ranks(x):
+        if world_size == 1:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        out = [torch.zeros_like(t) for _ in range(world_size)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def timed_blocks(one_step, steps, warmup, max_blocks=41):
+        """`warmup` untimed steps, then blocks of exactly `steps` steps, each between two fences; every
+        rank runs the same number of blocks (decided from the max-over-ranks time of the first)."""
+        for i in range(warmup):
+            one_step(i)
+        blocks, mine = [], []
+        count = 1
+        k = 0
+        while k < count:
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one_step(i)
+            fence()
+            dt = time.perf_counter() - t0
+            mine.append(dt)
+            blocks.append(max_over_ranks(dt))
+            if k == 0 and blocks[0] < MIN_BLOCK_SECONDS:
+                count = int(min(max_blocks, max(3, MIN_BLOCK_SECONDS / max(blocks[0], 1e-6)))) | 1  # odd: a true median
+            k += 1
+        return blocks, mine
+
+    # ---------------- headline: one launch per step, no communication ----------------
+    blocks, mine = timed_blocks(lambda i: sim.step_with_actions(pool[i % args.pool]), args.steps, args.warmup)
+    dt = statistics.median(blocks)
+    per_rank_ms = all_ranks(statistics.median(mine) / args.steps * 1e3)
+
+    # ---------------- N > 1: the step followed by the all-gather of the observation shards ----------------
+    gather = None
+    if world_size > 1 and not args.no_gather_leg:
+        gathered = torch.empty((world_size * n,) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
+        gsteps, gwarm = (min(args.steps, 3), 1) if rehearse else (args.steps, min(args.warmup, 10))
+
+        def gather_step(i):
+            sim.step_with_actions(pool[i % args.pool])
+            gather_worlds(obs, 0, out=gathered)  # one all_gather_into_tensor straight into the global (N, P, H, W, F) tensor
+        gblocks, gmine = timed_blocks(gather_step, gsteps, gwarm, max_blocks=9)
+        gdt = statistics.median(gblocks)
+        shard_bytes = obs.numel()
+        step_s, gstep_s = dt / args.steps, gdt / gsteps
+        gather = {"value": n * world_size * gsteps / gdt, "unit": "env-steps/s", "ms_per_step": gstep_s * 1e3, "steps": gsteps,
+                  "bytes_per_rank_per_step": shard_bytes, "gathered_bytes_per_rank_per_step": shard_bytes * world_size,
+                  "collective": "gloo all-gather staged through the host (rehearsal)" if rehearse
+                  else "all_gather_into_tensor of the world-major int8 slab (RCCL)",
+                  # what the collective adds to a step, and its bus bandwidth (every rank receives (G-1) shards)
+                  "gather_ms_per_step": (gstep_s - step_s) * 1e3,
+                  "busbw_GBps": shard_bytes * (world_size - 1) / (gstep_s - step_s) / 1e9 if gstep_s > step_s else None,
+                  "per_rank_ms_per_step": all_ranks(statistics.median(gmine) / gsteps * 1e3)}
+
+    # ---------------- roofline of the step kernel ----------------
+    # average launch duration: HIP events on the launch stream (torch's current stream is the stream
+    # the C ABI is handed) around back-to-back launches.  The queue never drains, so elapsed / launches
+    # is the kernel's duration (rocprofv3 --kernel-trace agrees within 1%, profiles/); bracketing every
+    # launch with its own event pair would add ~2 us of marker overhead to a ~10 us kernel.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    ev0.record()
-    for i in range(k_launch):
-        sim.step_with_actions(pool[i % args.pool])
-    ev1.record()
-    torch.cuda.synchronize()
-    kernel_ms_avg = ev0.elapsed_time(ev1) / k_launch
 
-    # extra, never `value`: the same random-policy workload with the actions drawn in the kernel and
-    # the worlds' state kept in LDS between steps (mrl_rollout_random)
-    fused = None
-    if world_size == 1 and args.fused_steps > 0:
-        sim.rollout_random(args.fused_steps, seed=99, first_step=0)
+    def launches_us(fn, launches):
         torch.cuda.synchronize()
         ev0.record()
-        sim.rollout_random(args.fused_steps, seed=99, first_step=args.fused_steps)
+        for i in range(launches):
+            fn(i)
         ev1.record()
         torch.cuda.synchronize()
-        fused_ms = ev0.elapsed_time(ev1)
-        fused = {"value": n * args.fused_steps / (fused_ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": args.fused_steps,
-                 "us_per_step": fused_ms * 1e3 / args.fused_steps,
-                 "note": "every step still writes its observation slab, rewards and dones"}
+        return ev0.elapsed_time(ev1) * 1e3 / launches
 
-    # extra, never `value`: the SAME workload (the pre-sampled resident action pool, in order) as one open-loop
-    # sequence per launch (mrl_step_sequence): what the per-step launches and the state round trips cost
-    seq = None
-    if world_size == 1 and args.fused_steps > 0:
+    k_launch = max(args.steps, MIN_ROOFLINE_LAUNCHES)
+    kernel_us = launches_us(lambda i: sim.step_with_actions(pool[i % args.pool]), k_launch)
+
+    extras = {}
+    single = world_size == 1 and not args.no_extras
+    stream = torch.cuda.current_stream().cuda_stream
+    peak_measured = None
+    if world_size == 1:
+        # on-box bandwidth probes (second denominator): float4 copy and write-only streams over 1 GiB
+        nbytes = 1 << 30
+        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        b = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        L = _lib.lib()
+
+        def probe(mode, reps=8):
+            _lib.check(L.mrl_probe_stream(a.data_ptr(), b.data_ptr(), nbytes, mode, local_rank, stream))
+            us = launches_us(lambda i: _lib.check(L.mrl_probe_stream(a.data_ptr(), b.data_ptr(), nbytes, mode, local_rank, stream)), reps)
+            return nbytes * (2 if mode == 0 else 1) / (us * 1e-6) / 1e9
+        peak_measured = {"copy_GBps": probe(0), "write_GBps": probe(1), "write_through_GBps": probe(2),
+                         "note": "float4 streams over 1 GiB (mrl_probe_stream): copy counts read + written bytes"}
+        del a, b
+
+    if single and args.fused_steps > 0:
+        # the same random-policy workload with the actions drawn in the kernel and the worlds' state kept
+        # in LDS between steps (mrl_rollout_random, SURVEY.md section 8f item 1): no state or action bytes
+        sim.rollout_random(args.fused_steps, seed=99, first_step=0)
+        us = launches_us(lambda i: sim.rollout_random(args.fused_steps, seed=99, first_step=args.fused_steps), 1) / args.fused_steps
+        bpw = P * C * F + 4 * P + 4
+        extras["fused_random_rollout"] = {
+            "value": n / (us * 1e-6), "unit": "env-steps/s", "steps_per_launch": args.fused_steps, "us_per_step": us,
+            "bytes_per_world_step": bpw, "achieved_GBps": bpw * n / (us * 1e-6) / 1e9, "frac": bpw * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "note": "every step still writes its observation slab, rewards and dones; state stays in LDS, actions are drawn in-kernel"}
+        # the SAME workload as the headline (the resident action pool, in order) as one open-loop sequence per launch
         k_seq = min(args.fused_steps, 512)
         seq_actions = torch.stack([pool[i % args.pool] for i in range(k_seq)]).contiguous()
         sim.step_sequence(seq_actions)
-        torch.cuda.synchronize()
-        ev0.record()
-        sim.step_sequence(seq_actions)
-        ev1.record()
-        torch.cuda.synchronize()
-        seq_ms = ev0.elapsed_time(ev1)
-        seq = {"value": n * k_seq / (seq_ms * 1e-3), "unit": "env-steps/s", "steps_per_launch": k_seq, "us_per_step": seq_ms * 1e3 / k_seq,
-               "note": "same resident action pool, one launch per sequence; every step still writes observations, rewards, dones"}
+        us = launches_us(lambda i: sim.step_sequence(seq_actions), 1) / k_seq
+        bpw = P * C * F + 4 * P + 4 + 4 * P
+        extras["action_sequence_per_launch"] = {
+            "value": n / (us * 1e-6), "unit": "env-steps/s", "steps_per_launch": k_seq, "us_per_step": us,
+            "bytes_per_world_step": bpw, "achieved_GBps": bpw * n / (us * 1e-6) / 1e9, "frac": bpw * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "note": "same resident action pool, one launch per sequence; every step still writes observations, rewards, dones"}
         del seq_actions
+
+    if single:
+        # the reference's own timed regions (SURVEY.md section 8d), on this engine's drop-in wrappers
+        from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
+        env = OvercookedMadrona(args.layout, n, local_rank, horizon=args.horizon)
+        acts64 = [p.to(torch.int64) for p in pool[:8]]  # the harness hands int64 actions (randint_like of a long tensor)
+        reps = max(args.steps, MIN_ROOFLINE_LAUNCHES)
+        for i in range(5):
+            env.n_step(acts64[i % 8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            env.n_step(acts64[i % 8])
+        torch.cuda.synchronize()
+        w_dt = (time.perf_counter() - t0) / reps
+        extras["wrapped_n_step"] = {"value": n / w_dt, "unit": "env-steps/s", "us_per_step": w_dt * 1e6, "steps": reps,
+                                    "note": "OvercookedMadrona.n_step(actions int64 (P,N,1)): scripts/overcooked_example.py:104-106"}
+        chosen = torch.zeros_like(env.static_actions)
+        g_dones, g_obs, g_rew = (torch.zeros_like(env.static_dones), torch.zeros_like(env.static_observations),
+                                 torch.zeros_like(env.static_rewards))
+
+        def isolated(i):
+            env.static_actions.copy_(chosen)
+            env.sim.step()
+            g_dones.copy_(env.static_dones)
+            g_obs.copy_(env.static_observations)
+            g_rew.copy_(env.static_rewards)
+        for i in range(5):
+            isolated(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            isolated(i)
+        torch.cuda.synchronize()
+        i_dt = (time.perf_counter() - t0) / reps
+        extras["isolated_with_copies"] = {"value": n / i_dt, "unit": "env-steps/s", "us_per_step": i_dt * 1e6, "steps": reps,
+                                          "note": "action copy + sim.step() + copies of done/obs/reward: scripts/overcooked_isolated_example.py:56-65"}
+        del g_obs
+        env.close()
+
+    large = None
+    if single and args.large_worlds > n:
+        # a launch far larger than the 256 MiB Infinity Cache: the kernel, not launch latency or cache residency
+        big_n = args.large_worlds
+        big = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=big_n, **params)
+        big_pool = [torch.randint(0, 6, (P, big_n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(4)]
+        for i in range(5):
+            big.step_with_actions(big_pool[i % 4])
+        us = launches_us(lambda i: big.step_with_actions(big_pool[i % 4]), 60)
+        gbps = big.bytes_per_world_step * big_n / (us * 1e-6) / 1e9
+        large = {"worlds": big_n, "kernel_us_avg": us, "value": big_n / (us * 1e-6), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
+                 "frac_of_measured_write_through": gbps / peak_measured["write_through_GBps"] if peak_measured else None}
+        big.close()
+        del big_pool
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
@@ -204,7 +343,18 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         bytes_per_launch = sim.bytes_per_world_step * n
-        achieved = bytes_per_launch / (kernel_ms_avg * 1e-3) / 1e9
+        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "kernel": sim.kernel_name, "kernel_us_avg": kernel_us, "bytes_per_world_step": sim.bytes_per_world_step,
+                    "bytes_per_launch": bytes_per_launch, "launches_timed": k_launch,
+                    "note": "peak = HBM spec; the 41 MB working set is rewritten in place every step and is smaller than the "
+                            "256 MiB Infinity Cache, so the spec peak is a nominal denominator here: see peak_measured and large_batch"}
+        if peak_measured:
+            roofline["peak_measured"] = peak_measured
+            roofline["frac_of_measured_write_through"] = achieved / peak_measured["write_through_GBps"]
+        if large:
+            roofline["large_batch"] = large
         out = {
             "metric": "env-steps/sec (whole node), Overcooked 32768 worlds, random policy",
             "value": n * world_size * args.steps / dt,
@@ -220,22 +370,31 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"Overcooked {args.layout}, {n} worlds per GPU, horizon {args.horizon}, "
                                    f"uniform random actions (pre-sampled pool of {args.pool}, resident in HBM)",
-                       "worlds_per_gpu": n, "obs_gather": bool(gathered is not None)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": sim.kernel_name, "kernel_us_avg": kernel_ms_avg * 1e3,
-                         "bytes_per_launch": bytes_per_launch, "launches_timed": k_launch},
+                       "worlds_per_gpu": n, "obs_gather": False},
+            "timing": {"blocks": len(blocks), "block_ms": [b * 1e3 for b in blocks], "reported": "median block",
+                       "per_rank_ms_per_step": per_rank_ms, "rank_min_ms_per_step": min(per_rank_ms), "rank_max_ms_per_step": max(per_rank_ms)},
+            "roofline": roofline,
         }
-        if fused is not None:
-            out["fused_random_rollout"] = fused
-        if seq is not None:
-            out["action_sequence_per_launch"] = seq
+        if world_size > 1:
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend,
+                            "rehearsal_on_one_gpu": bool(rehearse)}
+            if gather is not None:
+                out["obs_gather"] = gather
+        out.update(extras)
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     sim.close()
     if world_size > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run(args)
 
 
 if __name__ == "__main__":

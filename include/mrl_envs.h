@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MRL_ABI_VERSION 1
+#define MRL_ABI_VERSION 2
 
 /* return codes */
 enum {
@@ -206,11 +206,17 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 /* One environment step for every world: replaces Manager::step.
  * Hanabi and Cartpole number new episodes in ascending world order, which takes a
  * prefix sum over the worlds that finished.  mrl_step does it inside ONE launch:
- * each workgroup publishes its count and waits for the lower-numbered workgroups
- * (csrc/episode_scan.hpp explains why that wait cannot deadlock).  The wait is
+ * each workgroup takes a ticket (one atomic increment) as its index, publishes its
+ * count and waits for the lower tickets -- workgroups that are known to have started,
+ * so the wait ends whatever the dispatch order (csrc/episode_scan.hpp).  The wait is
  * bounded all the same; if it ever expired the SCAN_TIMEOUT tensor of the game
- * becomes nonzero and the episode numbers of that step are unspecified. */
+ * becomes nonzero, the episode numbers from that step on are unspecified, and every
+ * later mrl_step* / mrl_rollout_random on the simulator returns MRL_ERR_DEVICE
+ * (the host learns it from a word in mapped host memory: no device call, no sync). */
 int mrl_step(mrl_sim *sim, void *hip_stream);
+
+/* 1 if an in-kernel wait of an earlier call expired (see mrl_step), else 0.  Reads host memory only. */
+int mrl_scan_timed_out(const mrl_sim *sim);
 
 /* Same step, but actions are read from caller memory instead of the ACTION
  * tensor (same dtype/shape/layout, device pointer).  Saves the copy the
@@ -279,6 +285,19 @@ const char *mrl_kernel_name(const mrl_sim *sim);
 /* algorithmic HBM bytes one step moves per world */
 uint64_t mrl_bytes_per_world_step(const mrl_sim *sim);
 void mrl_destroy(mrl_sim *sim);
+
+/* Test and measurement knobs, consulted by the NEXT mrl_*_create (the library reads no environment
+ * variable).  Keys: overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.no_share,
+ * overcooked.variant, hanabi.variant, hanabi.no_persistent, cartpole.no_persistent, two_launch_step,
+ * inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
+ * No reference counterpart (the reference has MADRONA_* environment variables for its JIT cache only). */
+int mrl_debug_set(const char *key, int64_t value);
+
+/* Measurement aid for bench.py's roofline.peak_measured: one float4 stream over caller buffers on
+ * device gpu_id, enqueued on hip_stream.  mode 0: copy src -> dst (reads + writes bytes each);
+ * mode 1: fill dst, plain stores; mode 2: fill dst, write-through (sc1) stores like the step
+ * kernels' observation stream.  bytes: multiple of 16, buffers 16-byte aligned.  No reference counterpart. */
+int mrl_probe_stream(void *dst_dev, const void *src_dev, uint64_t bytes, int mode, int gpu_id, void *hip_stream);
 
 /* message of the last failing call on this thread ("" if none) */
 const char *mrl_last_error(void);

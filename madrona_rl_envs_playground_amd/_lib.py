@@ -28,8 +28,10 @@ SYMBOLS = [
     "mrl_overcooked_create", "mrl_hanabi_create", "mrl_cartpole_create", "mrl_step", "mrl_step_with_actions",
     "mrl_step_phase1", "mrl_step_phase2", "mrl_set_episode_counter", "mrl_reseed_shard", "mrl_tensor", "mrl_game",
     "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
-    "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence",
+    "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
+    "mrl_scan_timed_out",
 ]
+ABI_VERSION = 2  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
 
 class TensorDesc(ctypes.Structure):
@@ -105,8 +107,35 @@ def lib():
     L.mrl_destroy.restype = None
     L.mrl_last_error.restype = ctypes.c_char_p
     L.mrl_abi_version.restype = i32
+    L.mrl_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    L.mrl_probe_stream.argtypes = [vp, vp, ctypes.c_uint64, i32, i32, vp]
+    L.mrl_scan_timed_out.argtypes = [vp]
+    if L.mrl_abi_version() != ABI_VERSION:
+        raise MrlError(f"{LIB_PATH} implements ABI version {L.mrl_abi_version()}, this binding expects {ABI_VERSION}: "
+                       "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = L
     return L
+
+
+def debug_set(key, value):
+    """Test / measurement knob for the NEXT simulator created (``mrl_debug_set``); ``debug_set(None, 0)`` clears all."""
+    check(lib().mrl_debug_set(key.encode() if key is not None else None, int(value)))
+
+
+class debug_knobs:
+    """``with debug_knobs({"two_launch_step": 1}): sim = ...`` -- knobs apply to simulators created inside."""
+
+    def __init__(self, knobs):
+        self.knobs = dict(knobs)
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            debug_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        debug_set(None, 0)
+        return False
 
 
 def check(rc):

@@ -1,12 +1,41 @@
 // extern "C" entry points of libmrl_envs.so (include/mrl_envs.h).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <exception>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace mrl {
 
 static thread_local char g_error[512] = "";
+
+// mrl_debug_set: the knobs tests and measurement tools may turn (the library reads no environment variable)
+static const char *const kDebugKeys[] = {
+    "overcooked.wpw",        // worlds per wave (0 = chosen by the library)
+    "overcooked.whole_max",  // largest single-pass observation tile, bytes
+    "overcooked.lds_max",    // LDS budget per workgroup, bytes
+    "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
+    "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition
+    "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
+    "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
+    "cartpole.no_persistent",
+    "two_launch_step",       // 1: mrl_step as phase 1 + phase 2 launches (Hanabi, Cartpole)
+    "inject_scan_timeout",   // 1: the simulator's SCAN_TIMEOUT alarm is raised right after construction (tests of the error path)
+    "ablate",                // diagnostic build only: phase ablation mask
+    "stamps",                // diagnostic build only: in-kernel time stamps
+};
+static std::mutex g_debug_mutex;
+static std::map<std::string, int64_t> g_debug;
+
+int64_t debug_get(const char *key, int64_t fallback)
+{
+    std::lock_guard<std::mutex> lock(g_debug_mutex);
+    auto it = g_debug.find(key);
+    return it == g_debug.end() ? fallback : it->second;
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -59,11 +88,51 @@ static int need(const mrl_sim *sim)
         set_error("null simulator handle");
         return MRL_ERR_INVALID;
     }
-    // launches go to the simulator's device whatever the caller's current device is
-    // (one process may hold simulators on several GPUs)
-    int current = -1;
-    if (hipGetDevice(&current) == hipSuccess && current != sim->device) (void)hipSetDevice(sim->device);
     return MRL_OK;
+}
+
+// Entry of every call that advances the simulation: a bounded in-kernel wait that expired in an
+// earlier call (SCAN_TIMEOUT, episode_scan.hpp) left the episode numbering unspecified -- refuse to go on.
+static int need_healthy(const mrl_sim *sim)
+{
+    if (int rc = need(sim)) return rc;
+    if (sim->scan_timed_out()) {
+        set_error("an in-kernel wait of an earlier step expired (SCAN_TIMEOUT): episode numbers of this simulator are "
+                  "unspecified from that step on; destroy it and create a new one");
+        return MRL_ERR_DEVICE;
+    }
+    return MRL_OK;
+}
+
+// ---- roofline.peak_measured of bench.py: float4 streams over caller buffers ----
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int kMode>
+__global__ void __launch_bounds__(256) mrl_probe_stream_kernel(f32x4 *__restrict__ dst, const f32x4 *__restrict__ src, size_t chunks)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const f32x4 fill = {1.f, 2.f, 3.f, 4.f};
+    for (; i + 3 * stride < chunks; i += 4 * stride) {
+        f32x4 a = fill, b = fill, c = fill, d = fill;
+        if (kMode == 0) {
+            a = src[i];
+            b = src[i + stride];
+            c = src[i + 2 * stride];
+            d = src[i + 3 * stride];
+        }
+        if (kMode == 2) {  // write-through, like the observation stores of the step kernels
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i), "v"(a) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + stride), "v"(b) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 2 * stride), "v"(c) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 3 * stride), "v"(d) : "memory");
+        } else {
+            dst[i] = a;
+            dst[i + stride] = b;
+            dst[i + 2 * stride] = c;
+            dst[i + 3 * stride] = d;
+        }
+    }
+    for (; i < chunks; i += stride) dst[i] = kMode == 0 ? src[i] : fill;
 }
 
 }  // namespace mrl
@@ -79,6 +148,7 @@ int mrl_overcooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t
 {
     if (!out) return MRL_ERR_INVALID;
     *out = nullptr;
+    mrl::DeviceGuard on(gpu_id);  // the caller's current device is restored on return
     return guarded([&] { *out = mrl::create_overcooked(cfg, gpu_id, num_worlds); });
 }
 
@@ -86,6 +156,7 @@ int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_wor
 {
     if (!out) return MRL_ERR_INVALID;
     *out = nullptr;
+    mrl::DeviceGuard on(gpu_id);  // the caller's current device is restored on return
     return guarded([&] { *out = mrl::create_hanabi(cfg, gpu_id, num_worlds); });
 }
 
@@ -93,48 +164,56 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out)
 {
     if (!out) return MRL_ERR_INVALID;
     *out = nullptr;
+    mrl::DeviceGuard on(gpu_id);  // the caller's current device is restored on return
     return guarded([&] { *out = mrl::create_cartpole(gpu_id, num_worlds); });
 }
 
 int mrl_step(mrl_sim *sim, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->step(nullptr, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->step(actions_dev, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->phase1(actions_dev_or_null, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->phase2(episode_base_dev, (hipStream_t)hip_stream); });
 }
 
 int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->set_episode_counter(next_episode, (hipStream_t)hip_stream); });
 }
 
 int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_total, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->reseed_shard(world_offset, num_worlds_total, (hipStream_t)hip_stream); });
 }
 
 int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_steps, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     if (!actions_dev && num_steps) {
         mrl::set_error("mrl_step_sequence: null action array");
         return MRL_ERR_INVALID;
@@ -144,13 +223,15 @@ int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_ste
 
 int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream)
 {
-    if (int rc = mrl::need(sim)) return rc;
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->rollout_random(num_steps, seed, first_step, (hipStream_t)hip_stream); });
 }
 
 int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out)
 {
     if (int rc = mrl::need(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
     if (!out) return MRL_ERR_INVALID;
     int rc = MRL_OK;
     int g = guarded([&] {
@@ -171,9 +252,52 @@ uint64_t mrl_bytes_per_world_step(const mrl_sim *sim) { return sim ? sim->bytes_
 void mrl_destroy(mrl_sim *sim)
 {
     if (!sim) return;
-    (void)hipSetDevice(sim->device);
+    mrl::DeviceGuard on(sim->device);
     (void)hipDeviceSynchronize();
     delete sim;
+}
+
+int mrl_scan_timed_out(const mrl_sim *sim) { return sim && sim->scan_timed_out() ? 1 : 0; }
+
+int mrl_debug_set(const char *key, int64_t value)
+{
+    if (!key) {  // forget everything
+        std::lock_guard<std::mutex> lock(mrl::g_debug_mutex);
+        mrl::g_debug.clear();
+        return MRL_OK;
+    }
+    for (const char *known : mrl::kDebugKeys)
+        if (strcmp(known, key) == 0) {
+            std::lock_guard<std::mutex> lock(mrl::g_debug_mutex);
+            mrl::g_debug[key] = value;
+            return MRL_OK;
+        }
+    mrl::set_error("mrl_debug_set: unknown key '%s'", key);
+    return MRL_ERR_INVALID;
+}
+
+int mrl_probe_stream(void *dst_dev, const void *src_dev, uint64_t bytes, int mode, int gpu_id, void *hip_stream)
+{
+    if (!dst_dev || (mode == 0 && !src_dev) || mode < 0 || mode > 2 || bytes < 16 || (bytes & 15u) ||
+        (reinterpret_cast<uintptr_t>(dst_dev) & 15u) || (reinterpret_cast<uintptr_t>(src_dev) & 15u)) {
+        mrl::set_error("mrl_probe_stream: need 16-byte aligned device buffers, a multiple of 16 bytes and mode 0..2");
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(gpu_id);
+    return guarded([&] {
+        const size_t chunks = bytes / 16;
+        const unsigned grid = (unsigned)std::min<size_t>((chunks + 1023) / 1024, 256 * 16);
+        auto *dst = static_cast<mrl::f32x4 *>(dst_dev);
+        auto *src = static_cast<const mrl::f32x4 *>(src_dev);
+        hipStream_t stream = (hipStream_t)hip_stream;
+        if (mode == 0)
+            hipLaunchKernelGGL((mrl::mrl_probe_stream_kernel<0>), dim3(grid), dim3(256), 0, stream, dst, src, chunks);
+        else if (mode == 1)
+            hipLaunchKernelGGL((mrl::mrl_probe_stream_kernel<1>), dim3(grid), dim3(256), 0, stream, dst, src, chunks);
+        else
+            hipLaunchKernelGGL((mrl::mrl_probe_stream_kernel<2>), dim3(grid), dim3(256), 0, stream, dst, src, chunks);
+        MRL_HIP(hipGetLastError());
+    });
 }
 
 }  // extern "C"

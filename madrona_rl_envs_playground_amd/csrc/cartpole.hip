@@ -209,14 +209,18 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
                                                                   int32_t *__restrict__ done, unsigned long long *status,
                                                                   uint32_t epoch, const uint32_t *__restrict__ episode_base,
                                                                   uint32_t *__restrict__ next_counter,
-                                                                  uint32_t *__restrict__ reset_count, uint32_t *timed_out,
-                                                                  int32_t *action_out, uint64_t sample_seed, uint32_t sample_step)
+                                                                  uint32_t *__restrict__ reset_count, const mrl::Alarm timed_out,
+                                                                  int32_t *action_out, uint64_t sample_seed, uint32_t sample_step,
+                                                                  uint32_t *ticket, uint32_t ticket_base)
 {
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
-    const uint32_t first = blockIdx.x * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
-    const bool last_block = blockIdx.x == gridDim.x - 1;
+    __shared__ uint32_t s_ticket;
+    // the workgroup's index is a ticket, not blockIdx.x: see episode_scan.hpp
+    const uint32_t b = mrl::take_ticket(ticket, ticket_base, &s_ticket);
+    const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
+    const bool last_block = b == gridDim.x - 1;
     float4 s[kUnroll];
     int32_t a[kUnroll];
     const uint32_t base = *episode_base;
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     __syncthreads();
     uint32_t block_total = 0;
     for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
-    if (threadIdx.x == 0) mrl::publish_count(status, blockIdx.x, epoch, block_total);
+    if (threadIdx.x == 0) mrl::publish_count(status, b, epoch, block_total);
     __syncthreads();  // s_wave is reused below
     // everything that does not need the prefix goes out while the other workgroups publish
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     }
     if (block_total == 0 && !last_block) return;  // uniform per workgroup
     uint32_t grand_total = 0;
-    uint32_t running = mrl::wait_prefix(status, gridDim.x, blockIdx.x, epoch, s_red, last_block, &grand_total, timed_out);
+    uint32_t running = mrl::wait_prefix(status, gridDim.x, b, epoch, s_red, last_block, &grand_total, timed_out);
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {  // ascending world order: round u covers worlds first + 256 u ...
         uint32_t total;
@@ -278,8 +282,9 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
 // every step still writes state, reward, done and the drawn action.  Episode numbering needs the
 // same two grid-wide hand-offs per step as mrl_hanabi_rollout (hanabi.hip): the lower workgroups'
 // finished counts of this step (waited for) and everybody's counts of the previous step, through
-// a ring of four epoch-tagged status arrays.  All workgroups must be resident at once (checked on
-// the host, else one launch per step); waits are bounded (SCAN_TIMEOUT).
+// a ring of four epoch-tagged status arrays.  All workgroups must be resident at once: the host
+// launches it cooperatively (the runtime refuses a grid the device cannot hold) and otherwise runs
+// one launch per step; waits are bounded (SCAN_TIMEOUT).
 constexpr int kRing = 4;
 
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float4 *__restrict__ state, float *__restrict__ reward,
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
                                                                uint32_t first_step, uint64_t seed,
                                                                const uint32_t *__restrict__ episode_base,
                                                                uint32_t *__restrict__ next_counter,
-                                                               uint32_t *__restrict__ reset_count, uint32_t *timed_out)
+                                                               uint32_t *__restrict__ reset_count, const mrl::Alarm timed_out)
 {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
@@ -411,8 +416,11 @@ struct CartpoleSim final : mrl_sim {
     uint32_t parity = 0;
     // single-launch step (see mrl_cartpole_step_fused)
     unsigned long long *status = nullptr;
-    uint32_t *timed_out = nullptr;
+    mrl::AlarmOwner alarm;
+    uint32_t *ticket = nullptr;    // device: tickets handed out so far (episode_scan.hpp)
+    uint32_t tickets_issued = 0;   // host mirror: fused_grid per fused launch, mod 2^32
     uint32_t fused_grid = 0, epoch = 0;
+    bool scan_timed_out() const override { return alarm.raised(); }
 
     void step(const int32_t *actions, hipStream_t stream) override
     {
@@ -427,9 +435,10 @@ struct CartpoleSim final : mrl_sim {
     {
         epoch += 1;
         hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions, state,
-                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, timed_out,
-                           action_out, seed, sample_step);
+                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, alarm.alarm(),
+                           action_out, seed, sample_step, ticket, tickets_issued);
         MRL_HIP(hipGetLastError());
+        tickets_issued += fused_grid;
         parity ^= 1u;
     }
 
@@ -441,13 +450,23 @@ struct CartpoleSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (persistent_ok) {
-            hipLaunchKernelGGL(mrl_cartpole_rollout, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, state, reward, done, action,
-                               ring, ring_epoch + 1u, num_steps, first_step, seed, counter + parity, counter + (parity ^ 1u),
-                               reset_count, timed_out);
-            MRL_HIP(hipGetLastError());
-            ring_epoch += num_steps;
-            parity ^= 1u;
-            return;
+            // cooperative: the runtime checks the grid against what the device can hold at once and
+            // refuses it otherwise -- then, and from then on, one launch per step
+            uint32_t n = num_worlds, epoch0 = ring_epoch + 1u;
+            const uint32_t *base = counter + parity;
+            uint32_t *next = counter + (parity ^ 1u);
+            mrl::Alarm al = alarm.alarm();
+            void *args[] = {&n, &state, &reward, &done, &action, &ring, &epoch0, &num_steps, &first_step, &seed, &base, &next,
+                            &reset_count, &al};
+            const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_cartpole_rollout), dim3(fused_grid),
+                                                              dim3(kBlock), args, 0, stream);
+            if (err == hipSuccess) {
+                ring_epoch += num_steps;
+                parity ^= 1u;
+                return;
+            }
+            (void)hipGetLastError();  // clear it; the per-step path below needs no co-residency
+            persistent_ok = false;
         }
         for (uint32_t k = 0; k < num_steps; k++) {
             if (fused_grid) {
@@ -502,7 +521,7 @@ struct CartpoleSim final : mrl_sim {
         case MRL_CARTPOLE_REWARD: *out = mrl::make_desc(reward, MRL_FLOAT32, device, {N, 1}); return true;
         case MRL_CARTPOLE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {N, 1}); return true;
         case MRL_CARTPOLE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
-        case MRL_CARTPOLE_SCAN_TIMEOUT: *out = mrl::make_desc(timed_out, MRL_UINT32, device, {1}); return true;
+        case MRL_CARTPOLE_SCAN_TIMEOUT: *out = mrl::make_desc(alarm.alarm().dev, MRL_UINT32, device, {1}); return true;
         default: return false;
         }
     }
@@ -542,20 +561,25 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         {
             const uint32_t blocks = (num_worlds + kUnroll * kBlock - 1) / (kUnroll * kBlock);
-            if (blocks <= mrl::kMaxFusedBlocks && !getenv("MRL_TWO_LAUNCH_STEP")) {
+            if (blocks <= mrl::kMaxFusedBlocks && !mrl::debug_get("two_launch_step", 0)) {
                 sim->fused_grid = blocks;
                 sim->status = sim->arena.alloc<unsigned long long>(blocks);
             }
         }
-        sim->timed_out = sim->arena.alloc<uint32_t>(1);
+        sim->alarm.init(sim->arena);
+        sim->ticket = sim->arena.alloc<uint32_t>(1);
         if (sim->fused_grid) {
             int per_cu = 0, cus = 0;
             MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&mrl_cartpole_rollout), kBlock, 0));
             MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
-            sim->persistent_ok = !getenv("MRL_CARTPOLE_NO_PERSISTENT") && (uint64_t)sim->fused_grid <= (uint64_t)per_cu * (uint64_t)cus;
+            // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
+            // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)
+            const int usable = per_cu > 4 ? per_cu - 1 : per_cu;
+            sim->persistent_ok = !mrl::debug_get("cartpole.no_persistent", 0) && (uint64_t)sim->fused_grid <= (uint64_t)usable * (uint64_t)cus;
             sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->fused_grid);
         }
         sim->reseed_shard(0, num_worlds, 0);
+        if (mrl::debug_get("inject_scan_timeout", 0)) hipLaunchKernelGGL(mrl::raise_alarm_kernel, dim3(1), dim3(1), 0, 0, sim->alarm.alarm());
         MRL_HIP(hipDeviceSynchronize());
     } catch (...) {
         delete sim;

@@ -52,6 +52,68 @@ class DeviceArena {
     std::vector<void *> blocks_;
 };
 
+// Restores the caller's current device when a C-ABI call returns: launches go to the simulator's
+// device whatever the caller's current device is (one process may hold simulators on several
+// GPUs), and torch's idea of the current device must not change behind its back.
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+        if (previous_ != device) (void)hipSetDevice(device);
+        else previous_ = -1;  // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (previous_ >= 0) (void)hipSetDevice(previous_);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+
+  private:
+    int previous_ = -1;
+};
+
+// Test / measurement knobs set through mrl_debug_set (include/mrl_envs.h) and consulted by the NEXT
+// mrl_*_create.  The shipped library reads no environment variable.
+int64_t debug_get(const char *key, int64_t fallback);
+
+// Raised by a kernel whose bounded wait expired (episode_scan.hpp): one word in HBM (the exported
+// SCAN_TIMEOUT tensor) and one in host-mapped pinned memory, which the host looks at on every
+// later call without touching the device.
+struct Alarm {
+    uint32_t *dev = nullptr;
+    uint32_t *host = nullptr;
+    __device__ __forceinline__ void raise() const
+    {
+        *dev = 1u;
+        *host = 1u;
+    }
+};
+
+class AlarmOwner {
+  public:
+    ~AlarmOwner()
+    {
+        if (host_) (void)hipHostFree(host_);
+    }
+    void init(DeviceArena &arena)
+    {
+        alarm_.dev = arena.alloc<uint32_t>(1);
+        MRL_HIP(hipHostMalloc(reinterpret_cast<void **>(&host_), sizeof(uint32_t), hipHostMallocMapped));
+        *host_ = 0u;
+        void *mapped = nullptr;
+        MRL_HIP(hipHostGetDevicePointer(&mapped, host_, 0));
+        alarm_.host = static_cast<uint32_t *>(mapped);
+    }
+    const Alarm &alarm() const { return alarm_; }
+    bool raised() const { return host_ && *reinterpret_cast<volatile uint32_t *>(host_) != 0u; }
+
+  private:
+    Alarm alarm_{};
+    uint32_t *host_ = nullptr;
+};
+
 inline mrl_tensor_desc make_desc(void *data, int dtype, int device, std::initializer_list<int64_t> shape,
                                  std::initializer_list<int64_t> strides = {})
 {
@@ -108,6 +170,8 @@ struct mrl_sim {
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;
     virtual const char *kernel_name() const = 0;
     virtual uint64_t bytes_per_world_step() const = 0;
+    // a bounded in-kernel wait expired in an earlier call: episode numbers are unspecified from there on
+    virtual bool scan_timed_out() const { return false; }
 };
 
 namespace mrl {

@@ -17,6 +17,8 @@
 
 #include <cstdint>
 
+#include "common.hpp"
+
 namespace mrl {
 
 constexpr uint32_t kMaxScanBlocks = 1024;  // 4 workgroups per CU on MI355X
@@ -66,14 +68,41 @@ __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, ui
 // Single-launch variant.  Instead of ending the kernel between "count" and "prefix", every
 // workgroup publishes (epoch, count) in one 64-bit word and then waits until all lower-numbered
 // workgroups have published theirs for the same epoch (the host passes a fresh epoch per launch,
-// so the status words are never cleared).  A workgroup only ever waits for LOWER indices and
-// publishes before it waits, and workgroups are dispatched in index order on every XCD, so the
-// lowest unfinished workgroup never waits: the wait cannot deadlock whatever the occupancy.  As a
-// second line of defence the wait is bounded; on expiry *timed_out is set (the launch then
-// finishes with wrong episode numbers instead of hanging the GPU) and the host reports it.
+// so the status words are never cleared).
+//
+// Why the wait cannot deadlock, whatever the occupancy, the dispatch order and whatever else runs
+// on the GPU: a workgroup's index in this protocol is NOT blockIdx.x but a TICKET, the value one
+// atomic increment returned when the workgroup started (take_ticket below; the same device rocPRIM's
+// look-back scan uses).  A workgroup that holds ticket t therefore knows that tickets 0..t-1 were
+// handed out before, i.e. those workgroups are running or done.  It publishes before it waits
+// and waits only for lower tickets, so the lowest unfinished ticket never waits for anybody: by
+// induction every wait ends.  HIP promises nothing about dispatch order (MI355X_MICROARCH.md,
+// "Workgroup dispatch"), and nothing here assumes any.  The ticket also decides which worlds the
+// workgroup owns, so "ascending world order" and "ascending ticket" are the same order.
+// The wait is bounded all the same; on expiry the Alarm is raised (the launch then finishes with
+// wrong episode numbers instead of hanging the GPU) and every later call on the simulator fails.
+//
+// The persistent rollouts (mrl_*_rollout) are a different matter: there every workgroup waits for
+// EVERY other one at each step, which needs the whole grid resident at once.  They are launched
+// with hipLaunchCooperativeKernel, which refuses a grid the device cannot hold, and the host falls
+// back to one launch per step when it does.
 // ---------------------------------------------------------------------------------------------
+// test hook (mrl_debug_set "inject_scan_timeout"): raises the alarm exactly as an expired wait would
+static __global__ void raise_alarm_kernel(const Alarm alarm) { alarm.raise(); }
+
 constexpr uint32_t kMaxFusedBlocks = 4096;
 constexpr uint32_t kMaxPolls = 1u << 22;  // ~1 s of polling
+
+// One returning atomic per workgroup (thread 0), broadcast through LDS.  `ticket` counts up for
+// the simulator's whole life; `ticket_base` is its value when this launch started (the host
+// knows it: launches of one simulator never overlap and each hands out exactly gridDim.x
+// tickets), so the difference is this workgroup's index in the launch.  Ends with a barrier.
+__device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t ticket_base, uint32_t *s_slot)
+{
+    if (threadIdx.x == 0) *s_slot = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_slot);
+}
 
 __device__ __forceinline__ void publish_count(unsigned long long *status, uint32_t block, uint32_t epoch, uint32_t count)
 {
@@ -85,7 +114,7 @@ __device__ __forceinline__ void publish_count(unsigned long long *status, uint32
 // at: a one-at-a-time loop pays a full memory round trip per status word (8..16 of them per lane).
 template <int kBatch>
 __device__ __forceinline__ uint32_t read_counts(const unsigned long long *status, uint32_t first, uint32_t limit, uint32_t epoch,
-                                                uint32_t below, uint32_t *sum_below, uint32_t *timed_out,
+                                                uint32_t below, uint32_t *sum_below, const Alarm &timed_out,
                                                 uint32_t lane = threadIdx.x & 63u, uint32_t stride = 64u)
 {
     unsigned long long v[kBatch];
@@ -101,7 +130,7 @@ __device__ __forceinline__ uint32_t read_counts(const unsigned long long *status
         if (i < limit) {
             for (uint32_t polls = 0; (uint32_t)(v[j] >> 32) != epoch; polls++) {
                 if (polls == kMaxPolls) {
-                    *timed_out = 1u;
+                    timed_out.raise();
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -116,7 +145,7 @@ __device__ __forceinline__ uint32_t read_counts(const unsigned long long *status
 
 // whole workgroup; same contract as scan_prefix
 __device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
-                                                uint32_t *s_red, bool want_total, uint32_t *grand_total, uint32_t *timed_out)
+                                                uint32_t *s_red, bool want_total, uint32_t *grand_total, const Alarm &timed_out)
 {
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     uint32_t before = 0, all = 0;
@@ -148,7 +177,7 @@ __device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint
 // have been acknowledged (loads and stores share vmcnt, in issue order), so the wave that looks
 // back should do so before it streams out its own results.
 __device__ __forceinline__ uint32_t wave_wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
-                                                     bool want_total, uint32_t *grand_total, uint32_t *timed_out)
+                                                     bool want_total, uint32_t *grand_total, const Alarm &timed_out)
 {
     uint32_t before = 0, all = 0;
     const uint32_t limit = want_total ? num_blocks : block;

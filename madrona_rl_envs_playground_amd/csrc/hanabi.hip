@@ -113,13 +113,13 @@ struct HanabiParams {
 #ifdef MRL_DIAG
 #define STAMP(k)                                                                                                  \
     do {                                                                                                          \
-        if (p.stamps && lane == 0 && sub == blockIdx.x * p.chunk)                                                 \
-            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memtime();      \
+        if (p.stamps && lane == 0 && sub == bid * p.chunk)                                                 \
+            p.stamps[(size_t)(bid * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memtime();      \
     } while (0)
 #define STAMP_REALTIME(k)                                                                                         \
     do {                                                                                                          \
-        if (p.stamps && lane == 0 && sub == blockIdx.x * p.chunk)                                                 \
-            p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+        if (p.stamps && lane == 0 && sub == bid * p.chunk)                                                 \
+            p.stamps[(size_t)(bid * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
     } while (0)
 #define ABLATED(bit) (p.ablate & (bit))
 #else
@@ -974,22 +974,22 @@ struct FusedScan {
     unsigned long long *status;
     uint32_t epoch;
     uint32_t *s_part;  // LDS: [0] finished worlds before this workgroup, [1] on the whole GPU
-    uint32_t *timed_out;
+    mrl::Alarm timed_out;
 };
 
 template <int kV, bool kFused>
 __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, bool *last_over,
-                                              const FusedScan &scan)
+                                              const FusedScan &scan, const uint32_t bid)
 {
     constexpr int kR = kV ? 5 : 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keeps w0, nw and the row descriptors in SGPRs
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
-    const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
+    const uint32_t chunk_end = min(N, (bid + 1) * p.chunk);
     uint32_t finished = 0;
 
-    for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {
+    for (uint32_t sub = bid * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {
         const uint32_t w0 = sub + wib * kWorldsPerWave;
         const uint32_t nw = w0 < chunk_end ? min((uint32_t)kWorldsPerWave, chunk_end - w0) : 0u;
         STAMP(0);
@@ -1059,11 +1059,11 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
                 if (wib == kWavesPerBlock - 1) {
                     uint32_t total = 0;
                     for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
-                    if (lane == 0) mrl::publish_count(scan.status, blockIdx.x, scan.epoch, total);
-                    const bool last_block = blockIdx.x == gridDim.x - 1;
+                    if (lane == 0) mrl::publish_count(scan.status, bid, scan.epoch, total);
+                    const bool last_block = bid == gridDim.x - 1;
                     if (total != 0 || last_block) {
                         uint32_t grand = 0;
-                        const uint32_t before = mrl::wave_wait_prefix(scan.status, gridDim.x, blockIdx.x, scan.epoch, last_block, &grand, scan.timed_out);
+                        const uint32_t before = mrl::wave_wait_prefix(scan.status, gridDim.x, bid, scan.epoch, last_block, &grand, scan.timed_out);
                         if (lane == 0) {
                             scan.s_part[0] = before;
                             scan.s_part[1] = grand;
@@ -1108,7 +1108,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
     bool last_over;
-    const uint32_t total = step_body<kV, false>(p, smem, s_counts, &last_over, FusedScan{});
+    const uint32_t total = step_body<kV, false>(p, smem, s_counts, &last_over, FusedScan{}, blockIdx.x);
     if (threadIdx.x == 0) p.block_counts[blockIdx.x] = total;
 }
 
@@ -1117,19 +1117,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL
 // base + running + 1, ... in ascending world order, and write both agents' rows.
 template <bool kAll, int kV>
 __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, uint8_t *s_list, uint32_t base,
-                                           uint32_t running, bool have_flag = false, bool flag = false)
+                                           uint32_t running, const uint32_t bid, bool have_flag = false, bool flag = false)
 {
     constexpr int kR = kV ? 5 : 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keeps w0, nw and the row descriptors in SGPRs
     const WaveLds l = wave_lds(smem, wib);
     const uint32_t N = p.num_worlds;
-    const uint32_t chunk_end = min(N, (blockIdx.x + 1) * p.chunk);
+    const uint32_t chunk_end = min(N, (bid + 1) * p.chunk);
     // Finished worlds are sparse (a few per 64), so they are compacted over the workgroup first:
     // s_list holds their local indices in ascending order.  Entry e goes to wave e % 4, slot
     // e / 4, so the long serial re-deal runs on all four SIMDs instead of queueing in wave 0;
     // the two agents of a re-dealt world are then encoded by two lanes side by side.
-    for (uint32_t sub = blockIdx.x * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {  // uniform trip count
+    for (uint32_t sub = bid * p.chunk; sub < chunk_end; sub += kWorldsPerBlock) {  // uniform trip count
         const uint32_t local = wib * kWorldsPerWave + lane;
         // (the single-launch step hands over the flag it has just computed when the workgroup owns one sub-block)
         const bool over = lane < kWorldsPerWave && sub + local < chunk_end && (kAll || (have_flag ? flag : p.done[sub + local] != 0));
@@ -1207,7 +1207,7 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
         *reset_count = grand_total;
         *next_counter = base + grand_total;
     }
-    reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running);
+    reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running, blockIdx.x);
 }
 
 // The whole step in one launch (mrl_step on one GPU): transition, then the single-launch prefix
@@ -1216,16 +1216,19 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
 template <int kV>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
 mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
-                      uint32_t *next_counter, uint32_t *reset_count, uint32_t *timed_out)
+                      uint32_t *next_counter, uint32_t *reset_count, const mrl::Alarm timed_out, uint32_t *ticket, uint32_t ticket_base)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
     __shared__ uint32_t s_part[2 * kWavesPerBlock];
     __shared__ uint8_t s_list[kWorldsPerBlock];
-    const bool last_block = blockIdx.x == gridDim.x - 1;
+    __shared__ uint32_t s_ticket;
     const uint32_t base = *episode_base;  // requested now, needed after the transition
+    // the workgroup's index is a ticket, not blockIdx.x: see episode_scan.hpp
+    const uint32_t bid = mrl::take_ticket(ticket, ticket_base, &s_ticket);
+    const bool last_block = bid == gridDim.x - 1;
     bool last_over = false;
-    const uint32_t total = step_body<kV, true>(p, smem, s_counts, &last_over, FusedScan{status, epoch, s_part, timed_out});
+    const uint32_t total = step_body<kV, true>(p, smem, s_counts, &last_over, FusedScan{status, epoch, s_part, timed_out}, bid);
     if (total == 0 && !last_block) return;  // uniform for the workgroup
     const uint32_t running = s_part[0], grand_total = s_part[1];  // left by the last wave (barriers inside step_body)
     if (last_block && threadIdx.x == 0) {
@@ -1236,9 +1239,9 @@ mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t
     // a finished world), so the re-deal needs no ordering against the transition's stores.
 #ifdef MRL_DIAG
     if (p.stamps && (threadIdx.x & 63) == 0)
-        p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 7] = __builtin_amdgcn_s_memtime();
+        p.stamps[(size_t)(bid * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 7] = __builtin_amdgcn_s_memtime();
 #endif
-    reset_body<false, kV>(p, smem, s_counts, s_list, base, running, p.chunk == (uint32_t)kWorldsPerBlock, last_over);
+    reset_body<false, kV>(p, smem, s_counts, s_list, base, running, bid, p.chunk == (uint32_t)kWorldsPerBlock, last_over);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1253,15 +1256,15 @@ mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t
 // can run at most one step ahead of the slowest one (it needs everybody's previous-step count),
 // so a slot is never overwritten while somebody still reads it.  Unlike the single step this
 // kernel NEEDS all its workgroups resident at once (nobody exits before the last step): the host
-// launches it only if the whole grid fits the GPU and otherwise falls back to one launch per
-// step.  Waits are bounded as everywhere (SCAN_TIMEOUT).
+// launches it cooperatively (the runtime refuses a grid the device cannot hold at once) and falls
+// back to one launch per step when that fails.  Waits are bounded as everywhere (SCAN_TIMEOUT).
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 4;
 
 template <int kV>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
 mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoch0, uint32_t num_steps, uint32_t first_step,
-                   const uint32_t *episode_base, uint32_t *next_counter, uint32_t *reset_count, uint32_t *timed_out)
+                   const uint32_t *episode_base, uint32_t *next_counter, uint32_t *reset_count, const mrl::Alarm timed_out)
 {
     constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
@@ -1419,9 +1422,12 @@ struct HanabiSim final : mrl_sim {
     int variant = 0;  // code variant of the kernels (see encode_variant)
     // single-launch step (mrl_hanabi_step_fused)
     unsigned long long *status = nullptr;
-    uint32_t *timed_out = nullptr;
+    mrl::AlarmOwner alarm;
+    uint32_t *ticket = nullptr;   // device: tickets handed out so far (episode_scan.hpp)
+    uint32_t tickets_issued = 0;  // host mirror: `grid` per fused launch, mod 2^32
     uint32_t epoch = 0;
     bool fused = false;
+    bool scan_timed_out() const override { return alarm.raised(); }
 
     void step(const int32_t *actions, hipStream_t stream) override
     {
@@ -1435,11 +1441,12 @@ struct HanabiSim final : mrl_sim {
         const uint32_t *base = counter + parity;
         uint32_t *next = counter + (parity ^ 1u);
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, timed_out); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
         }
         MRL_HIP(hipGetLastError());
+        tickets_issued += grid;
         parity ^= 1u;
     }
 
@@ -1453,9 +1460,18 @@ struct HanabiSim final : mrl_sim {
         a.sample = 1;
         a.sample_seed = seed;
         a.action_out = action;
-        hipLaunchKernelGGL((mrl_hanabi_rollout<kV>), dim3(grid), dim3(kBlock), 0, stream, a, ring, ring_epoch + 1u, num_steps, first_step,
-                           counter + parity, counter + (parity ^ 1u), reset_count, timed_out);
-        MRL_HIP(hipGetLastError());
+        // cooperative: the runtime checks the grid against what the device can hold at once
+        uint32_t epoch0 = ring_epoch + 1u;
+        const uint32_t *base = counter + parity;
+        uint32_t *next = counter + (parity ^ 1u);
+        mrl::Alarm al = alarm.alarm();
+        void *args[] = {&a, &ring, &epoch0, &num_steps, &first_step, &base, &next, &reset_count, &al};
+        const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_hanabi_rollout<kV>), dim3(grid), dim3(kBlock),
+                                                          args, 0, stream);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         ring_epoch += num_steps;
         parity ^= 1u;
         return true;
@@ -1465,12 +1481,14 @@ struct HanabiSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (persistent_ok) {
+            bool launched;
             switch (variant) {
-            case 2: launch_rollout<2>(num_steps, seed, first_step, stream); break;
-            case 1: launch_rollout<1>(num_steps, seed, first_step, stream); break;
-            default: launch_rollout<0>(num_steps, seed, first_step, stream); break;
+            case 2: launched = launch_rollout<2>(num_steps, seed, first_step, stream); break;
+            case 1: launched = launch_rollout<1>(num_steps, seed, first_step, stream); break;
+            default: launched = launch_rollout<0>(num_steps, seed, first_step, stream); break;
             }
-            return;
+            if (launched) return;
+            persistent_ok = false;  // refused: one launch per step from now on (needs no co-residency)
         }
         const HanabiParams saved = params;
         params.sample = 1;
@@ -1556,7 +1574,7 @@ struct HanabiSim final : mrl_sim {
             return true;
         case MRL_HANABI_GAME: *out = mrl::make_desc(params.records, MRL_UINT8, device, {N, kRecordBytes}); return true;
         case MRL_HANABI_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
-        case MRL_HANABI_SCAN_TIMEOUT: *out = mrl::make_desc(timed_out, MRL_UINT32, device, {1}); return true;
+        case MRL_HANABI_SCAN_TIMEOUT: *out = mrl::make_desc(alarm.alarm().dev, MRL_UINT32, device, {1}); return true;
 #ifdef MRL_DIAG
         case 14:
             if (!params.stamps) return false;
@@ -1622,7 +1640,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         a.max_life = cfg->max_life_tokens;
         a.bpc = K * R;
         sim->variant = (K == 5 && R == 5 && a.max_info == 8 && a.max_life == 3) ? 2 : (R == 5 ? 1 : 0);
-        if (const char *env = getenv("MRL_HANABI_VARIANT")) sim->variant = std::min(sim->variant, atoi(env));  // tests: force the generic encoders
+        sim->variant = std::min(sim->variant, (int)mrl::debug_get("hanabi.variant", 2));  // tests: force the generic encoders
         a.max_deck = (4 + (R - 2) * 2) * K - 2 * kHand;
         a.off_flags = kHand * a.bpc;
         a.off_deck = a.off_flags + 2;
@@ -1656,17 +1674,18 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         a.done = sim->arena.alloc<int32_t>(N);
         a.block_counts = sim->arena.alloc<uint32_t>(sim->grid);
 #ifdef MRL_DIAG
-        a.ablate = getenv("MRL_ABLATE") ? (uint32_t)atoi(getenv("MRL_ABLATE")) : 0u;
-        a.stamps = getenv("MRL_STAMPS") ? sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16) : nullptr;
+        a.ablate = (uint32_t)mrl::debug_get("ablate", 0);
+        a.stamps = mrl::debug_get("stamps", 0) ? sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16) : nullptr;
 #endif
         sim->action = sim->arena.alloc<int32_t>((size_t)2 * N);
         sim->world_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
         sim->agent_id = sim->arena.alloc<int32_t>((size_t)2 * N, false);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
-        sim->timed_out = sim->arena.alloc<uint32_t>(1);
+        sim->alarm.init(sim->arena);
+        sim->ticket = sim->arena.alloc<uint32_t>(1);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
-        sim->fused = !getenv("MRL_TWO_LAUNCH_STEP");
+        sim->fused = !mrl::debug_get("two_launch_step", 0);
         {
             // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each
             // other: only usable when the grid fits the GPU in one go and each workgroup owns one sub-block
@@ -1676,13 +1695,17 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
                                                  : reinterpret_cast<const void *>(&mrl_hanabi_rollout<0>);
             MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0));
             MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
-            sim->persistent_ok = sim->fused && !getenv("MRL_HANABI_NO_PERSISTENT") && sim->params.chunk == (uint32_t)kWorldsPerBlock &&
-                                 (uint64_t)sim->grid <= (uint64_t)per_cu * (uint64_t)cus;
+            // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
+            // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)
+            const int usable = per_cu > 4 ? per_cu - 1 : per_cu;
+            sim->persistent_ok = sim->fused && !mrl::debug_get("hanabi.no_persistent", 0) && sim->params.chunk == (uint32_t)kWorldsPerBlock &&
+                                 (uint64_t)sim->grid <= (uint64_t)usable * (uint64_t)cus;
             sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->grid);
         }
         hipLaunchKernelGGL(fill_agent_ids, dim3((2 * N + 255) / 256), dim3(256), 0, 0, sim->world_id, sim->agent_id, N);
         MRL_HIP(hipGetLastError());
         sim->reseed_shard(0, N, 0);
+        if (mrl::debug_get("inject_scan_timeout", 0)) hipLaunchKernelGGL(mrl::raise_alarm_kernel, dim3(1), dim3(1), 0, 0, sim->alarm.alarm());
         MRL_HIP(hipDeviceSynchronize());
     } catch (...) {
         delete sim;

@@ -1250,7 +1250,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;
         a.steady = (a.wpp > 0 && ((uint64_t)a.wpp * a.block_bytes) % 16 == 0) ? 1u : 0u;
 #ifdef MRL_DIAG
-        a.ablate = getenv("MRL_ABLATE") ? (uint32_t)atoi(getenv("MRL_ABLATE")) : 0u;
+        a.ablate = (uint32_t)mrl::debug_get("ablate", 0);
         a.stamps = nullptr;
 #endif
         a.inv_p = P == 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)P) + 1u;  // x/1: umulhi(x, 2^32-1) == x-1 for x>0; handled in-kernel
@@ -1262,10 +1262,8 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // 9400 admits four worlds of a 9x5 layout (asymmetric_advantages: 25.4 -> 21.7 us per launch at 32768
         // worlds against two worlds per wave); larger tiles were measured and lose (8 worlds of a 5x5 layout:
         // 15.5 vs 12.4 us, 8 of counter_circuit 20.0 vs 16.7, 16 of cramped_room 12.8 vs 10.8)
-        uint32_t kWholeTileMax = 9400;
-        uint32_t lds_max = 65536;
-        if (const char *env = getenv("MRL_OVERCOOKED_WHOLE_MAX")) kWholeTileMax = (uint32_t)atoi(env);  // experiments
-        if (const char *env = getenv("MRL_OVERCOOKED_LDS_MAX")) lds_max = (uint32_t)atoi(env);
+        const uint32_t kWholeTileMax = (uint32_t)mrl::debug_get("overcooked.whole_max", 9400);  // knobs: experiments and tests only
+        const uint32_t lds_max = (uint32_t)mrl::debug_get("overcooked.lds_max", 65536);
         auto layout = [&](uint32_t wpw) {
             auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
             a.wpw = wpw;
@@ -1288,9 +1286,8 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // worlds per wave: as many as keep >= 4096 waves in the launch, fit 40 KB of LDS per
         // workgroup (>= 4 workgroups per CU) and keep the reciprocal divisions exact
         uint32_t wpw = 64;
-        if (const char *env = getenv("MRL_OVERCOOKED_WPW")) {
-            wpw = (uint32_t)atoi(env);
-            if (wpw < 1 || wpw > 64) wpw = 1;
+        if (const int64_t forced = mrl::debug_get("overcooked.wpw", 0)) {
+            wpw = (forced < 1 || forced > 64) ? 1u : (uint32_t)forced;
         } else {
             while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
             // the single-pass encode is worth more than wider groups (measured, 32768 worlds,
@@ -1317,13 +1314,13 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // shared / not: 2 players 9.4 / 10.3, 4 players 14.6 / 18.4, 8 players 36.8 / 32.6, 16 players 97 / 85,
         // 30 players 564 / 521 -- with many players the redundant transition (serial in the player count, one
         // active lane) costs more than the extra waves bring, so only up to four players.
-        a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= 4 && !getenv("MRL_OVERCOOKED_NO_SHARE")) ? 1u : 0u;
+        a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= 4 && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
         const uint32_t waves = a.share ? N * kWavesPerBlock : (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
 
 #ifdef MRL_DIAG
-        if (getenv("MRL_STAMPS")) a.stamps = sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16);
+        if (mrl::debug_get("stamps", 0)) a.stamps = sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16);
 #endif
         uint32_t *d_consts = sim->arena.alloc<uint32_t>(kConstBytes / 4, false);
         MRL_HIP(hipMemcpy(d_consts, consts, kConstBytes, hipMemcpyHostToDevice));

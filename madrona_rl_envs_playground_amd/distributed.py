@@ -30,6 +30,17 @@ def shard_range(total_worlds, rank, world_size):
     return lo, base + (1 if rank < extra else 0)
 
 
+def _all_gather_into(buf, piece, group=None):
+    """``all_gather_into_tensor``; device tensors under the ``gloo`` backend (one-GPU rehearsals of the
+    rank protocol, never a measured configuration) are staged through the host, which gloo can gather."""
+    if piece.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(buf.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host, piece.cpu(), group=group)
+        buf.copy_(host)
+    else:
+        dist.all_gather_into_tensor(buf, piece, group=group)
+
+
 def gather_worlds(local, world_dim=0, group=None, out=None, sizes=None):
     """All-gather ``local`` along ``world_dim``; every rank gets the global tensor.
 
@@ -48,7 +59,7 @@ def gather_worlds(local, world_dim=0, group=None, out=None, sizes=None):
     if sizes is None:
         direct = out is not None and world_dim == 0 and out.is_contiguous()
         buf = out if direct else torch.empty((ws * moved.shape[0],) + tail, dtype=moved.dtype, device=moved.device)
-        dist.all_gather_into_tensor(buf, moved, group=group)
+        _all_gather_into(buf, moved, group)
         if direct:
             return out
     else:
@@ -57,7 +68,7 @@ def gather_worlds(local, world_dim=0, group=None, out=None, sizes=None):
         padded = torch.zeros((biggest,) + tail, dtype=moved.dtype, device=moved.device)
         padded[:moved.shape[0]] = moved
         slabs = torch.empty((ws * biggest,) + tail, dtype=moved.dtype, device=moved.device)
-        dist.all_gather_into_tensor(slabs, padded, group=group)
+        _all_gather_into(slabs, padded, group)
         buf = torch.cat([slabs[r * biggest:r * biggest + int(s)] for r, s in enumerate(sizes)], dim=0)
     result = buf.movedim(0, world_dim)
     if out is not None:
@@ -105,12 +116,16 @@ class ShardedSimulator:
         self.sim.step_phase1(actions)
         mine = self._done_flags().sum().to(torch.int32).reshape(1)
         if self.world_size > 1:
-            dist.all_gather_into_tensor(self._counts, mine, group=self.group)
+            _all_gather_into(self._counts, mine, self.group)
         else:
             self._counts.copy_(mine)
         base = self._counter + self._counts[:self.rank].sum().to(torch.int32)
         self.sim.step_phase2(base)
         self._counter = self._counter + self._counts.sum().to(torch.int32)
+
+    def close(self):
+        """Destroys the rank-local simulator (raises if one of its steps hit SCAN_TIMEOUT)."""
+        self.sim.close()
 
     def gather(self, local, world_dim=0, out=None):
         sizes = None

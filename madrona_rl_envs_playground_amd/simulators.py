@@ -149,27 +149,35 @@ class _Simulator:
             _lib.check(rc)
 
     # --- extensions ----------------------------------------------------
+    def _action_pointer(self, actions, steps=None):
+        """Every entry point that hands the library a caller-owned action array goes through here: the
+        library reads raw int32 words, so dtype, layout, device and size are checked on this side."""
+        if not isinstance(actions, torch.Tensor) or not actions.is_cuda or actions.device.index != self.gpu_id:
+            raise ValueError(f"actions must be a tensor on cuda:{self.gpu_id} (the simulator's device)")
+        if actions.dtype != torch.int32 or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous int32 tensor on the simulator's device")
+        expect = self._action_numel if steps is None else steps * self._action_numel
+        if actions.numel() != expect:
+            raise ValueError(f"actions has {actions.numel()} elements, expected {expect}")
+        return actions.data_ptr()
+
     def step_with_actions(self, actions):
         """Step reading actions from ``actions`` (int32, the ACTION tensor's shape,
         contiguous, on this GPU) instead of the ACTION tensor."""
-        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device.index != self.gpu_id:
-            raise ValueError("actions must be a contiguous int32 tensor on the simulator's device")
-        if actions.numel() != self._action_numel:
-            raise ValueError(f"actions has {actions.numel()} elements, expected {self._action_numel}")
+        ptr = self._action_pointer(actions)
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
-        rc = self._L.mrl_step_with_actions(self._handle, actions.data_ptr(), stream)
+        rc = self._L.mrl_step_with_actions(self._handle, ptr, stream)
         if rc:
             _lib.check(rc)
 
     def step_sequence(self, actions):
         """One step per leading index of ``actions`` (int32, shape (K,) + ACTION tensor's shape, contiguous,
         on this GPU): same results as K ``step_with_actions`` calls (``mrl_step_sequence``)."""
-        if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device.index != self.gpu_id:
-            raise ValueError("actions must be a contiguous int32 tensor on the simulator's device")
-        if actions.dim() < 1 or actions.numel() != actions.shape[0] * self._action_numel:
-            raise ValueError(f"actions must hold K x {self._action_numel} elements, got shape {tuple(actions.shape)}")
+        if not isinstance(actions, torch.Tensor) or actions.dim() < 1:
+            raise ValueError("actions must hold K consecutive ACTION tensors")
+        ptr = self._action_pointer(actions, steps=int(actions.shape[0]))
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
-        _lib.check(self._L.mrl_step_sequence(self._handle, actions.data_ptr(), int(actions.shape[0]), stream))
+        _lib.check(self._L.mrl_step_sequence(self._handle, ptr, int(actions.shape[0]), stream))
 
     def rollout_random(self, num_steps, seed=0, first_step=0):
         """``num_steps`` steps under the uniform random policy, actions drawn on the
@@ -179,8 +187,9 @@ class _Simulator:
                                               stream))
 
     def step_phase1(self, actions=None):
+        ptr = self._action_pointer(actions) if actions is not None else None
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
-        _lib.check(self._L.mrl_step_phase1(self._handle, actions.data_ptr() if actions is not None else None, stream))
+        _lib.check(self._L.mrl_step_phase1(self._handle, ptr, stream))
 
     def step_phase2(self, episode_base=None):
         """``episode_base``: 1-element int32/uint32 CUDA tensor, or None for the
@@ -188,6 +197,11 @@ class _Simulator:
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
         ptr = episode_base.data_ptr() if episode_base is not None else None
         _lib.check(self._L.mrl_step_phase2(self._handle, ptr, stream))
+
+    @property
+    def scan_timed_out(self):
+        """True once a bounded in-kernel wait has expired (``mrl_scan_timed_out``); every later step raises."""
+        return bool(self._L.mrl_scan_timed_out(self._handle))
 
     def reseed_shard(self, world_offset, num_worlds_total):
         stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
@@ -215,9 +229,15 @@ class _Simulator:
         return self._tensors[slot]
 
     def close(self):
+        """Destroys the simulator.  Raises ``MrlError`` if one of its steps ran into SCAN_TIMEOUT (the
+        results since then carry unspecified episode numbers) -- after freeing it all the same."""
         if getattr(self, "_handle", None) is not None and self._handle.value:
+            bad = bool(self._L.mrl_scan_timed_out(self._handle))
             self._L.mrl_destroy(self._handle)
             self._handle = ctypes.c_void_p()
+            if bad:
+                raise MrlError("an in-kernel wait expired during this simulator's life (SCAN_TIMEOUT): "
+                               "episode numbers since then are unspecified")
 
     def __del__(self):
         try:

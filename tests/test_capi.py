@@ -25,7 +25,8 @@ def test_header_and_binding_list_agree():
 def test_library_exports_every_declared_symbol(hip_lib):
     for sym in declared_symbols():
         assert hasattr(hip_lib, sym), f"libmrl_envs.so does not export {sym}"
-    assert hip_lib.mrl_abi_version() == 1
+    from madrona_rl_envs_playground_amd import _lib
+    assert hip_lib.mrl_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_library_is_gfx950_only():
@@ -40,6 +41,29 @@ def test_null_handle_and_bad_slot_are_errors_not_crashes(hip_lib):
     assert hip_lib.mrl_step(None, None) != 0
     assert b"null simulator" in hip_lib.mrl_last_error()
     assert hip_lib.mrl_num_worlds(None) == 0
+
+
+def test_debug_knobs_are_an_explicit_call_not_the_environment(hip_lib):
+    """Tuning knobs go through mrl_debug_set; unknown keys are errors; the shipped sources read no
+    environment variable (a stray variable must not change the product's code path)."""
+    from madrona_rl_envs_playground_amd import _lib
+    _lib.debug_set("overcooked.wpw", 4)
+    _lib.debug_set(None, 0)
+    with pytest.raises(_lib.MrlError, match="unknown key"):
+        _lib.debug_set("overcooked.typo", 1)
+    csrc = os.path.join(REPO, "madrona_rl_envs_playground_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_abi_version_mismatch_is_refused(hip_lib, monkeypatch):
+    from madrona_rl_envs_playground_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 999)
+    with pytest.raises(_lib.MrlError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().mrl_abi_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -153,3 +153,45 @@ def test_device_random_policy(n, steps, hip_lib):
     for sim in (a, b, c):
         assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
         sim.close()
+
+
+def test_scan_timeout_is_an_error_not_a_silent_flag(hip_lib):
+    """A bounded in-kernel wait that expires leaves episode numbers unspecified: the calls after it
+    must fail (MRL_ERR_DEVICE -> MrlError) and close() must say so.  The alarm is raised by a test
+    hook (mrl_debug_set inject_scan_timeout) through the same device->host word a kernel would use."""
+    from madrona_rl_envs_playground_amd._lib import MrlError, debug_knobs
+    ok = make(2048)
+    ok.step()
+    assert not ok.scan_timed_out and int(ok.scan_timeout_tensor().to_torch().item()) == 0
+    with debug_knobs({"inject_scan_timeout": 1}):
+        bad = make(2048)
+    assert bad.scan_timed_out and int(bad.scan_timeout_tensor().to_torch().item()) == 1
+    for call in (bad.step, lambda: bad.step_with_actions(torch.zeros((2048, 1), dtype=torch.int32, device="cuda")),
+                 lambda: bad.rollout_random(3, seed=1), lambda: bad.step_phase1()):
+        with pytest.raises(MrlError, match="SCAN_TIMEOUT"):
+            call()
+    with pytest.raises(MrlError, match="SCAN_TIMEOUT"):
+        bad.close()
+    ok.step()  # other simulators are unaffected
+    ok.close()
+
+
+def test_action_arrays_are_validated_on_every_entry_point(hip_lib):
+    sim = make(512)
+    good = torch.zeros((512, 1), dtype=torch.int32, device="cuda")
+    for bad in (good.long(), good.cpu(), good[:100], torch.zeros((512, 2), dtype=torch.int32, device="cuda")[:, :1]):
+        for call in (sim.step_with_actions, sim.step_phase1):
+            with pytest.raises(ValueError):
+                call(bad)
+    sim.step_phase1(good)
+    sim.step_phase2()
+    sim.close()
+
+
+def test_current_device_is_restored(hip_lib):
+    """C-ABI calls bind the simulator's device and put the caller's back."""
+    before = torch.cuda.current_device()
+    sim = make(256)
+    sim.step()
+    assert torch.cuda.current_device() == before
+    sim.close()

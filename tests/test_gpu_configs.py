@@ -1,0 +1,214 @@
+"""GPU: BASELINE.json configs 4 and 5 and the multi-rank protocol.
+
+* config 4: every standard layout at the per-GPU shard of the 8-GPU run (32768 worlds): size-independent
+  properties on the whole batch plus a sampled lock-step against the oracle, like test_gpu_fullsize.py does
+  for cramped_room; `ShardedSimulator.gather` on a real simulator's tensor, single rank and as a two-rank
+  rehearsal on this one GPU (gloo; the driver's multi-GPU runs use one rank per GPU over RCCL);
+* config 5: the MAPPO rollout loop (tools/mappo_rollout_loop.py, reference train/MAPPO/main_player.py:211-261):
+  the observations the policy receives equal the oracle's for the actions the policies chose;
+* `python bench.py --gpus 2` starts its own ranks (rehearsal on one GPU) and prints one JSON line.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+from madrona_rl_envs_playground_amd import layouts  # noqa: E402
+from madrona_rl_envs_playground_amd.distributed import ShardedSimulator, shard_range  # noqa: E402
+from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator  # noqa: E402
+
+STANDARD = ["cramped_room", "asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("layout", STANDARD[1:])
+def test_standard_layout_full_shard(layout, hip_lib, oracle_lib):
+    """configs[3]'s per-GPU shard: 32768 worlds of each standard layout, uniform random actions."""
+    horizon, steps = 120, 150
+    params = layouts.get_base_layout_params(layout, horizon)
+    n, P, H, W = 32768, params["num_players"], params["height"], params["width"]
+    C, F = H * W, 5 * P + 16
+    sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+    obs = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    terrain = torch.tensor(params["terrain"][:C], device="cuda")
+    onehot = torch.zeros(C, 6, dtype=torch.int8, device="cuda")
+    nz = terrain > 0
+    onehot[nz, (terrain[nz] - 1)] = 1
+    sample = 48  # the first and the last `sample` worlds are also stepped by the oracle
+    orc = oracle_lib.OvercookedOracle(params, 2 * sample, num_threads=4)
+    torch.manual_seed(11)
+    total_reward = 0
+    for t in range(steps):
+        # interact-heavy stream so that pots fill and soups get served at this size too
+        a = torch.randint(0, 8, (P, n, 1), dtype=torch.int32, device="cuda").clamp_(max=5)
+        sim.step_with_actions(a)
+        orc.step(torch.cat([a[:, :sample, 0], a[:, n - sample:, 0]], dim=1).cpu().numpy())
+        if t % 25 == 0 or horizon - 2 <= t <= horizon:
+            o = obs
+            assert torch.equal(o[:, :, :, 5 * P:5 * P + 6], onehot.expand(n, P, C, 6))       # static terrain channels
+            assert (o[:, :, :, 0:P].sum(dim=2) == 1).all()                                  # each player on exactly one cell
+            assert (o[:, :, :, P:5 * P].sum(dim=(2, 3)) == P).all()                         # one orientation bit per player
+            assert (o[:, :, :, 0:P].sum(dim=3) * (terrain != 0).to(torch.int8)).sum() == 0  # players stand on floor
+            assert torch.equal(o[:, 0, :, 5 * P:], o[:, 1, :, 5 * P:])                      # tails are viewer-independent
+            assert torch.equal(o[:, 0, :, 0], o[:, 1, :, 1]) and torch.equal(o[:, 0, :, P:P + 4], o[:, 1, :, P + 4:P + 8])
+            ts = sim.state_timestep_tensor().to_torch()
+            assert (ts == (t + 1) % horizon).all()
+            assert torch.equal(o[:, 0, 0, F - 1].to(torch.int32), ((horizon - ts) < 40).to(torch.int32))
+        rew = sim.reward_tensor().to_torch()
+        assert torch.equal(rew[0], rew[1]) and (rew >= 0).all()
+        total_reward += int(rew[0].sum())
+        done = sim.done_tensor().to_torch()
+        assert bool(done.all()) == (t == horizon - 1) and bool(done.any()) == (t == horizon - 1)
+        got = torch.cat([obs[:sample], obs[n - sample:]]).cpu().numpy().astype(np.uint8)
+        assert np.array_equal(got.reshape(orc.obs.shape), orc.obs), f"sampled worlds differ from the oracle at step {t}"
+        assert np.array_equal(torch.cat([rew[:, :sample], rew[:, n - sample:]], dim=1).cpu().numpy(), orc.reward)
+    assert total_reward > 0
+    sim.close()
+
+
+def test_gather_on_a_real_simulator_single_rank(hip_lib):
+    """ShardedSimulator over an Overcooked simulator without a process group: the gather is the identity
+    on the world-major slab and the shard is the whole batch."""
+    params = layouts.get_base_layout_params("coordination_ring", 60)
+    total = 1000
+    sh = ShardedSimulator(lambda k: OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=k, **params), total,
+                          needs_episode_exchange=False)
+    assert (sh.lo, sh.n) == (0, total)
+    torch.manual_seed(3)
+    for _ in range(20):
+        sh.step(torch.randint(0, 6, (2, total, 1), dtype=torch.int32, device="cuda"))
+    local = sh.sim.observation_world_major_tensor().to_torch()
+    out = torch.empty_like(local)
+    got = sh.gather(local, world_dim=0, out=out)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(out, local)
+    assert sh.gather(sh.sim.reward_tensor().to_torch(), world_dim=1).shape == (2, total)
+    sh.close()
+
+
+def _gather_rank(rank, ws, port, layout, total, steps, out_dir):
+    """One rank of the two-rank rehearsal: its shard of a `total`-world batch on GPU 0, the global action
+    stream sliced like the worlds, observations/rewards/dones gathered with ShardedSimulator.gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, REPO)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        params = layouts.get_base_layout_params(layout, 40)
+        sh = ShardedSimulator(lambda k: OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=k, **params), total,
+                              needs_episode_exchange=False)
+        assert (sh.lo, sh.n) == shard_range(total, rank, ws)
+        gen = torch.Generator().manual_seed(77)  # same global stream on every rank
+        obs = sh.sim.observation_world_major_tensor().to_torch()
+        snaps = []
+        for t in range(steps):
+            a = torch.randint(0, 6, (2, total, 1), dtype=torch.int32, generator=gen)
+            sh.step(a[:, sh.lo:sh.lo + sh.n].contiguous().cuda())
+            if t % 9 == 0 or t == steps - 1:
+                full = sh.gather(obs, world_dim=0)
+                rew = sh.gather(sh.sim.reward_tensor().to_torch(), world_dim=1)
+                done = sh.gather(sh.sim.done_tensor().to_torch(), world_dim=0)
+                assert full.shape[0] == total and rew.shape == (2, total) and done.shape == (total,)
+                snaps.append((full.cpu(), rew.cpu(), done.cpu()))
+        if rank == 0:
+            torch.save(snaps, os.path.join(out_dir, "gathered.pt"))
+        sh.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4096, 1001], ids=["equal_shards", "ragged_shards"])
+def test_two_rank_gather_equals_one_simulator(total, hip_lib, tmp_path):
+    layout, steps, ws = "asymmetric_advantages", 50, 2
+    mp.start_processes(_gather_rank, args=(ws, _free_port(), layout, total, steps, str(tmp_path)), nprocs=ws, join=True,
+                       start_method="spawn")
+    snaps = torch.load(os.path.join(str(tmp_path), "gathered.pt"))
+    params = layouts.get_base_layout_params(layout, 40)
+    whole = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=total, **params)
+    gen = torch.Generator().manual_seed(77)
+    k = 0
+    for t in range(steps):
+        whole.step_with_actions(torch.randint(0, 6, (2, total, 1), dtype=torch.int32, generator=gen).cuda())
+        if t % 9 == 0 or t == steps - 1:
+            full, rew, done = snaps[k]
+            k += 1
+            assert torch.equal(full, whole.observation_world_major_tensor().to_torch().cpu()), f"step {t}"
+            assert torch.equal(rew, whole.reward_tensor().to_torch().cpu())
+            assert torch.equal(done, whole.done_tensor().to_torch().cpu())
+    assert k == len(snaps) and k > 3
+    whole.close()
+
+
+def test_bench_starts_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2 ...` without a launcher: rc 0 and ONE JSON line from rank 0 with the
+    no-communication `value` and the obs_gather leg (one-GPU rehearsal: both ranks on this card, gloo)."""
+    env = dict(os.environ, MRL_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["ranks"] == {"world_size": 2, "backend": "gloo", "rehearsal_on_one_gpu": True}
+    assert out["value"] > 0 and out["config"]["obs_gather"] is False
+    g = out["obs_gather"]
+    assert g["value"] > 0 and g["bytes_per_rank_per_step"] == 32768 * 1040 and len(g["per_rank_ms_per_step"]) == 2
+    assert len(out["timing"]["per_rank_ms_per_step"]) == 2 and out["timing"]["blocks"] >= 3
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["launches_timed"] >= 300
+
+
+@pytest.mark.parametrize("layout", ["cramped_room", "counter_circuit"])
+def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, oracle_lib):
+    """configs[4]: the loop of train/MAPPO/main_player.py:211-261 over the drop-in env.  Both players act
+    through CNN policies on the int8 observations; replaying the actions they chose through the oracle
+    must reproduce exactly the observations each policy was shown, the rewards and the dones."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import mappo_rollout_loop as loop
+    n, horizon, steps = 512, 30, 75
+    env, ego, buffers = loop.build(layout, n, horizon=horizon, steps_in_buffer=16, seed=5)
+    partner = env.partners[0][0]
+    ego.keep_inputs = partner.keep_inputs = True
+    params = layouts.get_base_layout_params(layout, horizon)
+    P, H, W = 2, params["height"], params["width"]
+    F = 5 * P + 16
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=4)
+
+    def as_env_view(o):  # oracle rows (n, P, C, F) -> per player (n, W, H, F), the wrapper's view
+        return o.reshape(n, P, H, W, F).transpose(0, 1, 3, 2, 4)
+
+    seen = {"steps": 0, "dones": 0}
+
+    def check(t, ob_in, ego_action, ob_out, rew, done):
+        want = as_env_view(orc.obs)
+        assert np.array_equal(ego.last_obs.cpu().numpy().astype(np.uint8), want[:, 0]), f"ego obs differs at step {t}"
+        assert np.array_equal(partner.last_obs.cpu().numpy().astype(np.uint8), want[:, 1]), f"partner obs differs at step {t}"
+        acts = np.stack([ego.last_action[:, 0].cpu().numpy(), partner.last_action[:, 0].cpu().numpy()]).astype(np.int32)
+        orc.step(acts)
+        assert np.array_equal(rew.cpu().numpy(), orc.reward[0]) and np.array_equal(done.cpu().numpy(), orc.done)
+        assert np.array_equal(ob_out.obs.cpu().numpy().astype(np.uint8), as_env_view(orc.obs)[:, 0])
+        assert torch.equal(buffers["obs"][t % 16], ob_out.obs)
+        seen["steps"] += 1
+        seen["dones"] += int(done.sum())
+
+    ob = env.reset()
+    loop.rollout(env, ego, buffers, ob, steps, on_step=check)
+    assert seen["steps"] == steps and seen["dones"] == 2 * n  # two horizons crossed
+    env.close()

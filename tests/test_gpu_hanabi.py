@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from madrona_rl_envs_playground_amd import hanabi_spec  # noqa: E402
+from madrona_rl_envs_playground_amd._lib import debug_knobs  # noqa: E402
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator  # noqa: E402
 
 FULL = dict(colors=5, ranks=5, players=2, max_information_tokens=8, max_life_tokens=3)
@@ -99,16 +100,15 @@ def test_rejects_bad_config(hip_lib):
         make(dict(FULL, players=3), 8)
 
 
-def test_full_game_encoder_matches_generic_encoder(hip_lib, monkeypatch):
+def test_full_game_encoder_matches_generic_encoder(hip_lib):
     """The full game runs a specialised encoder (constant section offsets, assembled in
     registers); the generic one is what the oracle lock-step covers on the small configurations,
     including the shifted encoding when information tokens exceed their maximum (sim.cpp:676-678).
     Same states, same actions -> identical tensors, also with token counts 9..13 injected."""
     n = 3000
     fast = make(FULL, n)
-    monkeypatch.setenv("MRL_HANABI_VARIANT", "0")
-    slow = make(FULL, n)
-    monkeypatch.delenv("MRL_HANABI_VARIANT")
+    with debug_knobs({"hanabi.variant": 0}):
+        slow = make(FULL, n)
     gen = torch.Generator(device="cuda").manual_seed(5)
 
     def tensors(sim):
@@ -165,15 +165,14 @@ def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
 
 
 @pytest.mark.parametrize("two_launch", [False, True], ids=["single_launch", "two_launch"])
-def test_device_random_policy(two_launch, hip_lib, oracle_lib, monkeypatch):
+def test_device_random_policy(two_launch, hip_lib, oracle_lib):
     """mrl_rollout_random == the oracle fed the documented stream (uniform over the mover's legal
     moves, include/mrl_envs.h): checked step by step, then a multi-step call against a replay."""
     from madrona_rl_envs_playground_amd.simulators import random_hanabi_action
-    if two_launch:
-        monkeypatch.setenv("MRL_TWO_LAUNCH_STEP", "1")
     n, seed = 2500, 0xC0FFEE1234
-    sim, orc = make(FULL, n), oracle_lib.HanabiOracle(FULL, n, num_threads=8)
-    twin = make(FULL, n)
+    with debug_knobs({"two_launch_step": 1} if two_launch else {}):
+        sim, twin = make(FULL, n), make(FULL, n)
+    orc = oracle_lib.HanabiOracle(FULL, n, num_threads=8)
     world = np.arange(n)
     hist = np.zeros(20, np.int64)
     for t in range(90):
@@ -227,13 +226,12 @@ def test_long_games_reach_the_empty_deck(hip_lib, oracle_lib):
 
 
 @pytest.mark.parametrize("cfg,n", [(FULL, 65536), (FULL, 10000 + 37), (SMALL, 4096)], ids=["full_65536", "full_ragged", "small"])
-def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib, monkeypatch):
+def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib):
     """mrl_rollout_random keeps the records in LDS for all steps of a call (one launch) when the
     grid fits the GPU; forced back to one launch per step it must leave identical tensors."""
     one = make(cfg, n)
-    monkeypatch.setenv("MRL_HANABI_NO_PERSISTENT", "1")
-    many = make(cfg, n)
-    monkeypatch.delenv("MRL_HANABI_NO_PERSISTENT")
+    with debug_knobs({"hanabi.no_persistent": 1}):
+        many = make(cfg, n)
     names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor",
              "done_tensor", "game_tensor", "reset_count_tensor", "action_tensor"]
     step = 0

@@ -5,6 +5,8 @@ import os, sys, torch
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
+from madrona_rl_envs_playground_amd import _lib
+_lib.debug_set("ablate", int(os.environ.get("MRL_ABLATE", "0")))  # the tool's own command-line knob
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator
 n = 65536
 sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,

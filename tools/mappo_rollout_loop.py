@@ -40,15 +40,53 @@ class CNNBase(nn.Module):
 class PolicyAgent(VectorAgent):
     def __init__(self, actor, critic):
         self.actor, self.critic = actor, critic
+        self.keep_inputs = False  # tests: keep a copy of every observation this policy is shown
 
     @torch.no_grad()
     def get_action(self, obs, record=True):
         logits = self.actor(obs.obs)
         self.value = self.critic(obs.state)
-        return torch.distributions.Categorical(logits=logits).sample().unsqueeze(-1)
+        if self.keep_inputs:  # obs.obs is a view of the simulator's buffer, which the next step overwrites
+            self.last_obs = obs.obs.clone()
+        self.last_action = torch.distributions.Categorical(logits=logits).sample().unsqueeze(-1)
+        return self.last_action
 
     def update(self, rewards, dones):
         return None
+
+
+def build(layout, n, gpu_id=0, horizon=400, steps_in_buffer=200, seed=0):
+    """The env, the two policy-driven players and a rollout buffer, wired as the reference's
+    MainPlayer does (train/MAPPO/main_player.py:73-112); returns (env, ego, buffers)."""
+    torch.manual_seed(seed)
+    env = OvercookedMadrona(layout, n, gpu_id, horizon=horizon)
+    w, h, f = env.width, env.height, 5 * env.num_players + 16
+    actor, critic = CNNBase(w, h, f).cuda(), CNNBase(w, h, f, out=1).cuda()
+    ego = PolicyAgent(actor, critic)
+    for _ in range(env.num_players - 1):
+        env.add_partner_agent(PolicyAgent(actor, critic))
+    T = steps_in_buffer
+    buffers = {"obs": torch.empty((T, n, w, h, f), dtype=torch.int8, device="cuda"),
+               "rew": torch.empty((T, n), dtype=torch.int32, device="cuda"),
+               "done": torch.empty((T, n), dtype=torch.int32, device="cuda")}
+    return env, ego, buffers
+
+
+def rollout(env, ego, buffers, ob, steps, on_step=None):
+    """`steps` iterations of MainPlayer.next_step (main_player.py:211-261): policy forward for the ego
+    (the partner's runs inside env.step), env.step, clone into the buffer slot.  `on_step(t, ob_in,
+    ego_action, ob_out, rew, done)` lets a test look at what the policy received."""
+    T = buffers["obs"].shape[0]
+    for t in range(steps):
+        act = ego.get_action(ob)
+        nxt, rew, done, _ = env.step(act)
+        buffers["obs"][t % T].copy_(nxt.obs)          # the reference clones obs/state, then chooseinsert()s
+        buffers["rew"][t % T].copy_(rew)
+        buffers["done"][t % T].copy_(done)
+        if on_step is not None:
+            on_step(t, ob, act, nxt, rew, done)
+        ob = nxt
+    return ob
 
 
 def main():
@@ -57,31 +95,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--layout", default="cramped_room")
     args = ap.parse_args()
-    n = args.worlds
-    env = OvercookedMadrona(args.layout, n, 0)
-    w, h, f = env.width, env.height, 5 * env.num_players + 16
-    actor, critic = CNNBase(w, h, f).cuda(), CNNBase(w, h, f, out=1).cuda()
-    ego = PolicyAgent(actor, critic)
-    env.add_partner_agent(PolicyAgent(actor, critic))
-    T = args.steps
-    buf_obs = torch.empty((T, n, w, h, f), dtype=torch.int8, device="cuda")
-    buf_rew = torch.empty((T, n), dtype=torch.int32, device="cuda")
-    buf_done = torch.empty((T, n), dtype=torch.int32, device="cuda")
+    n, T = args.worlds, args.steps
+    env, ego, buffers = build(args.layout, n, steps_in_buffer=T)
     ob = env.reset()
-
-    def loop(steps):
-        nonlocal ob
-        for t in range(steps):
-            act = ego.get_action(ob)
-            ob, rew, done, _ = env.step(act)
-            buf_obs[t % T].copy_(ob.obs)             # the reference clones obs/state, then chooseinsert()s
-            buf_rew[t % T].copy_(rew)
-            buf_done[t % T].copy_(done)
-
-    loop(10)
+    ob = rollout(env, ego, buffers, ob, 10)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loop(T)
+    ob = rollout(env, ego, buffers, ob, T)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rand = torch.randint(0, 6, (env.num_players, n, 1), device="cuda")

@@ -5,6 +5,8 @@ _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import layouts
+from madrona_rl_envs_playground_amd import _lib
+_lib.debug_set("ablate", int(os.environ.get("MRL_ABLATE", "0")))  # the tool's own command-line knob
 from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 params = layouts.get_base_layout_params("cramped_room", 400)

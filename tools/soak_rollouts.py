@@ -7,22 +7,22 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madrona_rl_envs_playground_amd._lib import debug_knobs  # noqa: E402
 from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, ExecMode, HanabiSimulator  # noqa: E402
 
 FULL = dict(colors=5, ranks=5, players=2, max_information_tokens=8, max_life_tokens=3)
 
 
-def pair(make, env_name):
+def pair(make, knob):
     a = make()
-    os.environ[env_name] = "1"
-    b = make()
-    del os.environ[env_name]
+    with debug_knobs({knob: 1}):
+        b = make()
     return a, b
 
 
 def main():
     steps, chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 30000, 997
-    a, b = pair(lambda: HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=65536, **FULL), "MRL_HANABI_NO_PERSISTENT")
+    a, b = pair(lambda: HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=65536, **FULL), "hanabi.no_persistent")
     done = 0
     while done < steps:
         k = min(chunk, steps - done)
@@ -35,7 +35,7 @@ def main():
     print("hanabi", done, "steps x 65536 worlds: persistent == per-step launches")
     a.close(); b.close()
 
-    a, b = pair(lambda: CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=1 << 20), "MRL_CARTPOLE_NO_PERSISTENT")
+    a, b = pair(lambda: CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=1 << 20), "cartpole.no_persistent")
     done = 0
     while done < steps:
         k = min(chunk, steps - done)

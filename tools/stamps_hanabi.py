@@ -1,9 +1,10 @@
 """Per-wave phase timeline of mrl_hanabi_step (diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag)."""
 import os, sys, torch, numpy as np
-os.environ["MRL_STAMPS"] = "1"
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
+from madrona_rl_envs_playground_amd import _lib
+_lib.debug_set("stamps", 1)
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
