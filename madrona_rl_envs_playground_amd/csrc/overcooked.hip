@@ -20,16 +20,21 @@
 // the algorithmic 41 MB per launch but spent ~540 instructions per world, mostly
 // wave-uniform transition logic running on 64 lanes for one world, and was
 // issue/latency bound at 21 us).  Now a wave owns `wpw` consecutive worlds:
-//   load     all lanes copy the group's state slab HBM -> LDS (contiguous, coalesced)
-//   step     lane = world: the serial transition of its world on its LDS slice
-//   store    all lanes copy the slab back
-//   observe  all lanes: the group's wpw*P*C observation rows, 64 rows per pass:
-//            zero-fill an LDS tile, patch the few non-zero bytes of each row,
-//            stream the tile out with 16-byte stores (the group's rows are one
-//            contiguous range of HBM)
-// so the transition costs 1/wpw of a wave per world and the encode runs with all
-// lanes busy whatever the layout size.  wpw is picked on the host so that a launch
-// still has thousands of waves (wpw = 1 for very large layouts).
+//   load     all lanes copy the group's state slab HBM -> LDS (contiguous, coalesced); while the
+//            loads are in flight the observation tile in LDS is filled with the group's static
+//            BACKGROUND (terrain one-hot bytes, everything else zero), an image built on the host
+//   step     lane = (world, player): every player's interaction, move proposal and collision test
+//            at once; same-cell interactions in ascending player id by rank, like the reference's
+//            four do_counter_pot_int phases; pairs exchange through DPP (P = 2) or LDS (any P)
+//   observe  only DYNAMIC cells (an object on them or a player standing there; typically a few per
+//            world) are compacted into a list with wave ballots, and one lane per (dynamic cell,
+//            viewer) patches that row of the tile; the tile is streamed out with 16-byte
+//            write-through stores (the group's rows are one contiguous range of HBM)
+//   store    state slab, rewards, flags
+// so the transition costs one pass of straight-line code per group whatever the player count, the
+// encode touches what changed and the stream-out runs with all lanes busy.  wpw is picked on the
+// host so that a launch still has thousands of waves (wpw = 1 for very large layouts), wpw*P <= 64.
+// Layouts whose group slab does not fit one LDS tile keep the multi-pass row assembly below.
 //
 // HBM layout, all world-major so a group's loads and
 // stores are contiguous and a shard of worlds is one contiguous slab:
@@ -93,7 +98,10 @@ struct StepParams {
                            // steps it redundantly, takes every kWavesPerBlock-th pass of its rows; wave 0 stores the state
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
-    uint32_t off_pl, off_act, off_cur, off_flags, off_tail, off_tile;  // byte offsets inside a wave's LDS region
+    uint32_t patch;        // single-pass encode over a background image: the group's slab starts on a 16-byte boundary
+    uint32_t bg_bytes;     // bytes of the background image (wpw worlds)
+    const uint32_t *bg;    // device: background image of one group, 16-byte padded
+    uint32_t off_pl, off_x, off_sum, off_cur, off_flags, off_list, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
     const uint32_t *consts;  // kConstBytes, device
@@ -301,10 +309,6 @@ __device__ __forceinline__ uint32_t interact(const StepParams &p, int32_t need, 
     return new_held;
 }
 
-// Transition with a compile-time player count: the players live in registers, every LDS read
-// that does not depend on an earlier write (player records, actions, terrain of the faced and
-// of the target cells) is issued up front, and only the faced cells' objects are touched in
-// order.  Same semantics as `transition` below.
 // The 16 viewer-independent bytes of a cell's observation rows, row[5P .. 5P+16): terrain
 // one-hot (6), idle pot onions/tomatoes, soup onions/tomatoes, remaining time, ready, dish,
 // onion, tomato, urgency (sim.cpp:79-120,151-164; terrain bytes :642-645).  `o` is the object on
@@ -338,135 +342,116 @@ __device__ __forceinline__ uint4 cell_tail(const StepParams &p, uint32_t terr, u
     return t;
 }
 
+// Value of the neighbouring lane of a pair (lanes 2k and 2k+1 swap): DPP quad_perm [1,0,3,2], no LDS.
+// Called with all lanes enabled.
+__device__ __forceinline__ uint32_t swap_pair(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// The transition of a whole group at once: lane = (world wl of the group, player q), lane = wl*P + q
+// (sim.cpp:199-438).  `posori` = pos | orientation << 8 and `held` are the lane's own player in
+// registers; the cells' objects are in LDS (s_obj, [wpw][C]).  kP == 2: pairs exchange through DPP;
+// kP == 0: any player count, through the scratch arrays s_x (>= 128 words), s_sum, s_blk (one word per world).
+//   interactions  sources and the serving window touch nobody else's state.  Counter / pot
+//                 interactions on the same cell happen in ascending player id: a player's RANK is the
+//                 number of lower ids facing its cell (setup_interact_time, sim.cpp:259-283) and
+//                 round r runs the players of rank r (do_counter_pot_int0..3, sim.cpp:285-358); rounds
+//                 nobody takes part in are skipped with one ballot.
+//   movement      every lane proposes (sim.cpp:363-379); any two equal proposals or any swapping pair
+//                 in a world and nobody in it moves (sim.cpp:383-426).
+// Inactive lanes (beyond the group's players) run along with harmless values.  Returns the
+// reward of the lane's WORLD (summed over its players) through reward_world.
 template <int kP>
-__device__ __forceinline__ int32_t transition_fixed(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
-                                                    const uint8_t *s_pots, uint32_t *obj, uint32_t *pl, const uint8_t *act)
+__device__ __forceinline__ void transition_lanes(const StepParams &p, const uint8_t *s_terrain, uint32_t *s_obj, uint32_t *s_x,
+                                                 uint32_t *s_sum, uint32_t *s_blk, uint32_t P, uint32_t lane, bool active, uint32_t wl,
+                                                 uint32_t q, uint32_t a, uint32_t &posori, uint32_t &held, int32_t &reward_world)
 {
-    uint32_t posori[kP], held[kP], a[kP], tgt[kP], terr[kP], ahead[kP];
-#pragma unroll
-    for (int q = 0; q < kP; q++) {
-        posori[q] = pl[2 * q] & 0xFFFFu;
-        held[q] = pl[2 * q + 1];
-        a[q] = act[q];
+    const uint32_t C = p.C;
+    const uint32_t pos = posori & 0xFFu, ori = (posori >> 8) & 0xFFu;
+    const uint32_t tgt = pos + (uint32_t)step_of(ori, p.deltas);
+    const uint32_t terr = s_terrain[tgt];
+    const uint32_t ahead = s_terrain[pos + (uint32_t)step_of(a, p.deltas)];  // STAY / INTERACT: own cell (AIR)
+    const bool inter = active && a == A_INTERACT;
+    const bool touches = inter && (terr == T_COUNTER || terr == T_POT);
+    const uint32_t key = touches ? tgt : 0xFFFFu;
+    const uint32_t base = wl * P;
+    uint32_t rank = 0;
+    if constexpr (kP == 2) {
+        const uint32_t other = swap_pair(key);
+        rank = (q == 1u && touches && other == tgt) ? 1u : 0u;
+    } else {
+        s_x[lane] = key;
+        wave_lds_sync();
+        for (uint32_t q2 = 0; q2 + 1 < P; q2++) rank += (q2 < q && touches && s_x[base + q2] == key) ? 1u : 0u;
+        wave_lds_sync();
     }
+    int32_t mine = 0;
+    const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held));
+    uint32_t *cell = s_obj + (touches ? wl * C + tgt : 0u);
+    constexpr uint32_t kRounds = kP == 2 ? 2u : 4u;  // at most four players face one cell
 #pragma unroll
-    for (int q = 0; q < kP; q++) {
-        const uint32_t pos = posori[q] & 0xFF, ori = posori[q] >> 8;
-        tgt[q] = pos + (uint32_t)step_of(ori, p.deltas);
-        terr[q] = s_terrain[tgt[q]];
-        ahead[q] = s_terrain[pos + (uint32_t)step_of(a[q], p.deltas)];  // STAY / INTERACT: own cell (AIR)
-    }
-    // (Reading every touched object up front and forwarding later writers in registers was
-    // tried: no faster -- this phase is bound by instruction issue on 8 active lanes, not by
-    // the LDS round trips.)
-    int32_t reward = 0;
-#pragma unroll
-    for (int q = 0; q < kP; q++) {
-        if (a[q] != A_INTERACT) continue;
-        const bool touches = terr[q] == T_COUNTER || terr[q] == T_POT;
-        uint32_t there = touches ? obj[tgt[q]] : kItemNone;
-        const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(there));
-        const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held[q]));
-        held[q] = interact(p, need, value, terr[q], held[q], there, reward);
-        if (touches) obj[tgt[q]] = there;
-    }
-    uint32_t pos[kP], prop[kP], pori[kP];
-#pragma unroll
-    for (int q = 0; q < kP; q++) {
-        pos[q] = posori[q] & 0xFF;
-        const uint32_t ori = posori[q] >> 8;
-        prop[q] = pos[q];
-        pori[q] = ori;
-        if (a[q] != A_INTERACT) {
-            pori[q] = a[q] == A_STAY ? ori : a[q];
-            prop[q] = ahead[q] != T_AIR ? pos[q] : pos[q] + (uint32_t)step_of(a[q], p.deltas);
+    for (uint32_t r = 0; r < kRounds; r++) {
+        const bool todo = inter && rank == r;
+        if (r > 0 && __ballot(todo) == 0ull) break;
+        if (todo) {
+            uint32_t there = touches ? *cell : kItemNone;
+            const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(there));
+            held = interact(p, need, value, terr, held, there, mine);
+            if (touches) *cell = there;
         }
+        wave_lds_sync();
     }
-    bool blocked = false;
-#pragma unroll
-    for (int x = 0; x < kP; x++)
-#pragma unroll
-        for (int y = x + 1; y < kP; y++) blocked |= (prop[x] == prop[y]) | ((prop[x] == pos[y]) & (pos[x] == prop[y]));
-#pragma unroll
-    for (int q = 0; q < kP; q++) {
-        pl[2 * q] = (blocked ? pos[q] : prop[q]) | (pori[q] << 8);
-        pl[2 * q + 1] = held[q];
+    // movement proposal; orientation := action unless STAY / INTERACT
+    uint32_t prop = pos, pori = ori;
+    {
+        const bool moves = a != A_INTERACT;
+        const uint32_t np = pos + (uint32_t)step_of(a, p.deltas);
+        pori = (moves && a != A_STAY) ? a : ori;
+        prop = (moves && ahead == T_AIR) ? np : pos;
     }
-    // pots (sim.cpp:430-438), after the interactions: a pot started this step is already at 1
-    for (uint32_t k = 0; k < p.num_pots; k++) {
-        const uint32_t c = k < 4 ? (p.pots_w >> (8 * k)) & 0xFFu : (uint32_t)s_pots[k];
-        const uint32_t o = obj[c];
-        const int32_t tick = (int8_t)(o >> 24);
-        if ((o & 0xFF) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o)))
-            obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+    bool blocked;
+    if constexpr (kP == 2) {
+        reward_world = mine + (int32_t)swap_pair((uint32_t)mine);
+        const uint32_t o = swap_pair(pos | (prop << 8));
+        const uint32_t opos = o & 0xFFu, oprop = o >> 8;
+        blocked = (prop == oprop) | ((prop == opos) & (pos == oprop));
+    } else {
+        s_x[lane] = pos | (prop << 8);
+        if (active && q == 0) {
+            s_sum[wl] = 0u;
+            s_blk[wl] = 0u;
+        }
+        wave_lds_sync();
+        if (mine != 0) atomicAdd(&s_sum[wl], (uint32_t)mine);
+        bool hit = false;
+        for (uint32_t q2 = 0; q2 < P; q2++) {
+            const uint32_t v = s_x[base + q2];
+            hit |= (q2 != q) & ((prop == (v >> 8)) | ((prop == (v & 0xFFu)) & (pos == (v >> 8))));
+        }
+        if (hit && active) s_blk[wl] = 1u;
+        wave_lds_sync();
+        reward_world = active ? (int32_t)s_sum[wl] : 0;
+        blocked = active && s_blk[wl] != 0u;
+        wave_lds_sync();
     }
-    return reward;
+    posori = (blocked ? pos : prop) | (pori << 8);
 }
 
-// One world's transition, run by one lane on its LDS slice (sim.cpp:199-489).
-// pl[2q] = pos | ori<<8 (| proposed pos<<16 | proposed ori<<24 while moving), pl[2q+1] = held item.
-__device__ __forceinline__ int32_t transition(const StepParams &p, const uint8_t *s_terrain, const uint8_t *s_times,
-                                              const uint8_t *s_values, const uint8_t *s_pots, uint32_t *obj,
-                                              uint32_t *pl, const uint8_t *act)
+// Pots (sim.cpp:430-438), after the interactions: a pot started in this step is already at 1.  Lane = world.
+__device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_pots, uint32_t *s_obj, uint32_t nw, uint32_t lane)
 {
-    const uint32_t P = p.P;
-    int32_t reward = 0;
-    // interactions, ascending player id (sim.cpp:208-358)
-    for (uint32_t q = 0; q < P; q++) {
-        if (act[q] != A_INTERACT) continue;
-        const uint32_t posori = pl[2 * q];
-        const uint32_t tgt = (posori & 0xFF) + (uint32_t)step_of((posori >> 8) & 0xFF, p.deltas);
-        const uint32_t terr = s_terrain[tgt];
-        const bool touches = terr == T_COUNTER || terr == T_POT;
-        uint32_t there = touches ? obj[tgt] : kItemNone;
-        const uint32_t before = there;
-        const uint32_t in_hand = pl[2 * q + 1];
-        pl[2 * q + 1] = interact(p, (int32_t)s_times[recipe_of(there)], (int32_t)s_values[recipe_of(in_hand)], terr, in_hand, there,
-                                 reward);
-        if (touches && there != before) obj[tgt] = there;
-    }
-
-    // movement proposals (sim.cpp:363-379)
-    for (uint32_t q = 0; q < P; q++) {
-        const uint32_t a = act[q], posori = pl[2 * q] & 0xFFFFu;
-        const uint32_t pos = posori & 0xFF, ori = posori >> 8;
-        uint32_t prop = pos, pori = ori;
-        if (a != A_INTERACT) {
-            const uint32_t np = pos + (uint32_t)step_of(a, p.deltas);
-            pori = a == A_STAY ? ori : a;
-            prop = s_terrain[np] != T_AIR ? pos : np;
-        }
-        pl[2 * q] = posori | (prop << 16) | (pori << 24);
-    }
-    // all-or-nothing collision rule (sim.cpp:383-426): same target, or two players swapping cells
-    bool blocked = false;
-    for (uint32_t a = 0; a + 1 < P; a++) {
-        const uint32_t ra = pl[2 * a];
-        const uint32_t pos_a = ra & 0xFF, prop_a = (ra >> 16) & 0xFF;
-        for (uint32_t b = a + 1; b < P; b++) {
-            const uint32_t rb = pl[2 * b];
-            const uint32_t pos_b = rb & 0xFF, prop_b = (rb >> 16) & 0xFF;
-            blocked |= (prop_a == prop_b) | ((prop_a == pos_b) & (pos_a == prop_b));
-        }
-    }
-    for (uint32_t q = 0; q < P; q++) {
-        const uint32_t r = pl[2 * q];
-        const uint32_t pos = blocked ? (r & 0xFF) : ((r >> 16) & 0xFF);
-        pl[2 * q] = pos | ((r >> 24) << 8);
-    }
-
-    // pots (sim.cpp:430-438): after the interactions, so a pot started now is already at 1
-    for (uint32_t k = 0; k < p.num_pots; k++) {
-        const uint32_t c = s_pots[k];
-        const uint32_t o = obj[c];
-        if ((o & 0xFF) == O_SOUP) {
+    if (lane < nw) {
+        uint32_t *obj = s_obj + lane * p.C;
+        for (uint32_t k = 0; k < p.num_pots; k++) {
+            const uint32_t c = k < 4 ? (p.pots_w >> (8 * k)) & 0xFFu : (uint32_t)s_pots[k];
+            const uint32_t o = obj[c];
             const int32_t tick = (int8_t)(o >> 24);
-            if (tick >= 0 && tick < (int32_t)s_times[recipe_of(o)]) obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+            if ((o & 0xFF) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o)))
+                obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
         }
     }
-    return reward;
 }
-
 // Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
 __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset, const uint4 &v)
@@ -551,6 +536,122 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
 }
 
+// Single-pass encode over a BACKGROUND image (p.patch; see the header of this file).  `tile` already
+// holds the group's static rows (terrain one-hot bytes, zeros elsewhere) and starts on a 16-byte
+// boundary like the group's slab in HBM.  What changes from step to step is confined to the cells
+// with an object on them or a player standing there: those are compacted into s_list with wave
+// ballots, and one lane per (dynamic cell, viewer) overwrites that row's 16-byte tail and sets the
+// two player bytes; rows of worlds in their last 40 steps get the urgency byte in a pass of their own.
+// the group's dynamic cells, compacted in ascending order into s_list; returns how many (wave-uniform)
+__device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint32_t *s_obj, const uint8_t *s_cur, uint16_t *s_list,
+                                                 uint32_t nw, uint32_t lane)
+{
+    const uint32_t ncells = nw * p.C;
+    uint32_t ndyn = 0;
+    for (uint32_t i0 = 0; i0 < ncells; i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < ncells;
+        const uint32_t o = s_obj[valid ? i : 0u];
+        const uint32_t who = s_cur[valid ? i : 0u];
+        const bool dyn = valid && (((o & 0xFFu) != O_NONE) | (who != 0xFFu));
+        const unsigned long long m = __ballot(dyn);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (dyn) s_list[ndyn + before] = (uint16_t)i;
+        ndyn += (uint32_t)__popcll(m);
+    }
+    wave_lds_sync();
+    return ndyn;
+}
+
+template <int kP>
+__device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
+                                              const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
+                                              const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t nw,
+                                              uint32_t lane)
+{
+    const uint32_t C = p.C, F = p.F, shift = 5 * P;
+#ifdef MRL_DIAG
+    if (p.ablate & 8u) return;  // diagnostic build: no encode at all
+#endif
+    const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
+    const uint32_t nent = ndyn * P;
+    for (uint32_t j = lane; j < nent; j += kWave) {
+        const uint32_t k = kP == 2 ? j >> 1 : (P == 1u ? j : __umulhi(j, p.inv_p));
+        const uint32_t v = j - k * P;
+        const uint32_t i = s_list[k];
+        const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+        const uint32_t terr = s_terrain[c];
+        const uint32_t o = s_obj[i];
+        const uint32_t who = s_cur[i];
+        const uint32_t urgent = s_flags[l];
+        const bool occupied = who != 0xFF;
+        const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
+        const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
+        const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
+        const uint4 t = cell_tail(p, terr, o, h, urgent);
+        uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
+        lds_store_tail_even(row + shift, t);  // this path is only taken for even P: every tail is 2-byte aligned
+        if (occupied) {
+            const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+            row[rel] = 1;
+            row[P + 4 * rel + w_ori] = 1;
+        }
+    }
+    // urgency channel (sim.cpp:79-83) of the rows that were not patched; one in ten steps at horizon 400
+    if (__ballot(lane < nw && s_flags[lane & (kWave - 1)] != 0) != 0ull) {
+        const uint32_t nrows = nw * p.rows;
+        for (uint32_t r = lane; r < nrows; r += kWave) {
+            const uint32_t l = __umulhi(r, p.inv_rows);
+            if (s_flags[l]) tile[__umul24(r, F) + F - 1u] = 1;
+        }
+    }
+    wave_lds_sync();
+#ifdef MRL_DIAG
+    if (p.ablate & 2u) return;  // diagnostic build: encode in LDS, no stores to HBM
+#endif
+    // stream the slab out: 16-byte body as raw buffer stores over exactly the body (chunks past its end are
+    // dropped by the bounds check, so the four-deep batches need no per-lane branches), then the odd tail bytes
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    const uint32_t nbytes = nw * p.block_bytes;
+    const uint32_t body = nbytes >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs, 0, (int)(body << 4), 0x00020000);
+    for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+        const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+        const uint32_t last = body - 1u;
+        const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+        stream_store_rsrc(out, ka << 4, va);
+        stream_store_rsrc(out, kb << 4, vb);
+        stream_store_rsrc(out, kc << 4, vc);
+        stream_store_rsrc(out, kd << 4, vd);
+    }
+    const uint32_t done_bytes = body << 4;
+    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+}
+
+// The background image of the group -> the tile, through registers: requested with the state loads (one
+// latency), written to LDS once they are in.  Chunks beyond the image read as zero (buffer bounds check).
+constexpr int kBgChunksPerLane = 10;  // 64 lanes x 10 x 16 bytes >= the largest single-pass tile (9400 bytes)
+struct BgRegs {
+    u32x4 c[kBgChunksPerLane];
+};
+__device__ __forceinline__ void bg_request(const StepParams &p, uint32_t lane, BgRegs &r)
+{
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.bg), 0, (int)p.bg_bytes, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < kBgChunksPerLane; k++)
+        r.c[k] = __builtin_amdgcn_raw_buffer_load_b128(img, (int)((lane + (uint32_t)k * kWave) << 4), 0, 0);
+}
+__device__ __forceinline__ void bg_deliver(const StepParams &p, uint32_t lane, const BgRegs &r, uint8_t *tile)
+{
+    const uint32_t nchunks = p.bg_bytes >> 4;
+#pragma unroll
+    for (int k = 0; k < kBgChunksPerLane; k++) {
+        const uint32_t idx = lane + (uint32_t)k * kWave;
+        if (idx < nchunks) reinterpret_cast<u32x4 *>(tile)[idx] = r.c[k];
+    }
+}
+
 #ifdef MRL_DIAG
 #define STAMP(k)                                                                                               \
     do {                                                                                                       \
@@ -587,8 +688,6 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
-    const uint8_t *s_times = smem + kConstTimes;
-    const uint8_t *s_values = smem + kConstValues;
     const uint8_t *s_start = smem + kConstStart;
     const uint8_t *s_pots = smem + kConstPots;
 
@@ -604,16 +703,25 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
     uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);                 // [wpw][C]
     uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);       // [wpw][P][2]
-    uint8_t *s_act = wbase + p.off_act;                                    // [wpw][P]
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(wbase + p.off_x);         // [128] scratch of the transition
+    uint32_t *s_sum = reinterpret_cast<uint32_t *>(wbase + p.off_sum);     // [2][wpw]
+    uint32_t *s_blk = s_sum + p.wpw;
     uint8_t *s_cur = wbase + p.off_cur;                                    // [wpw][C] cell -> player
-    uint8_t *s_flags = wbase + p.off_flags;                                // [wpw]
+    uint8_t *s_flags = wbase + p.off_flags;                                // [64] urgency per world
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(wbase + p.off_list);   // [wpw][C] dynamic cells
     uint4 *s_tail = reinterpret_cast<uint4 *>(wbase + p.off_tail);         // [wpw][C]
     uint8_t *s_tile = wbase + p.off_tile;
 
     const uint32_t P = kP > 0 ? (uint32_t)kP : p.P, C = p.C, N = p.num_worlds;
     const uint32_t ncells = nw * C, nplayers = nw * P;
+    // lane = (world of the group, player)
+    const uint32_t wl = kP == 2 ? lane >> 1 : (P == 1u ? lane : __umulhi(lane, p.inv_p));
+    const uint32_t q = lane - wl * P;
+    const bool active = lane < nplayers;
 
+    uint32_t posori = 0, held = kItemNone, act = A_STAY;
     int32_t t_loaded = 0;
+    BgRegs bgr;
     // ---------------- load: HBM slab -> LDS (straight copies) ----------------
     // All global loads of the group are issued before the first one is consumed (explicitly
     // batched: a plain copy loop waits for each load before issuing the next, which measured
@@ -623,21 +731,21 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint2 *g_pl = p.players + (size_t)w0 * P;
         constexpr int kBatch = 4;
         uint32_t cell_reg[kBatch];
-        uint2 pl_reg = make_uint2(0, 0);
-        uint32_t act_reg[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
             cell_reg[k] = i < ncells ? g_obj[i] : 0u;
         }
-        if (lane < nplayers) pl_reg = g_pl[lane];
-#pragma unroll
-        for (int k = 0; k < kBatch; k++) act_reg[k] = (lane < nw && (uint32_t)k < P) ? (uint32_t)p.actions[(size_t)k * N + w0 + lane] : 0u;
-        // requested last and unconditionally (clamped index): behind a branch hipcc consumes it on the spot,
-        // `s_waitcnt vmcnt(0)` before the other loads of the group are even issued -- one more HBM latency
-        t_loaded = p.timestep[min(w0 + lane, N - 1u)];
-        // while the loads are in flight: zero the observation tile of the single-pass encode
-        if (p.whole) {
+        // unconditional, clamped indices: behind a branch hipcc consumes a load on the spot (`s_waitcnt vmcnt(0)`
+        // before the other loads of the group are even issued -- one more HBM latency)
+        const uint2 pl_reg = g_pl[active ? lane : 0u];
+        const uint32_t a_raw = (uint32_t)p.actions[(size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u)];
+        t_loaded = p.timestep[min(w0 + wl, N - 1u)];
+        if (p.patch) bg_request(p, lane, bgr);
+        // while the loads are in flight: the cell -> player map starts empty; without a background image the
+        // tile of the single-pass encode starts zeroed
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (p.whole && !p.patch) {
             const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;  // covers any start misalignment
             for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
         }
@@ -647,70 +755,62 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
             if (i < ncells) s_obj[i] = cell_reg[k];
         }
         for (uint32_t i = lane + kBatch * kWave; i < ncells; i += kWave) s_obj[i] = g_obj[i];
-        if (lane < nplayers) reinterpret_cast<uint2 *>(s_pl)[lane] = pl_reg;
-        for (uint32_t i = lane + kWave; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
-        if (lane < nw) {
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-                if ((uint32_t)k < P) s_act[lane * P + k] = (uint8_t)(act_reg[k] <= A_INTERACT ? act_reg[k] : (uint32_t)A_STAY);
-            for (uint32_t q = kBatch; q < P; q++) {
-                const uint32_t a = (uint32_t)p.actions[(size_t)q * N + w0 + lane];
-                s_act[lane * P + q] = (uint8_t)(a <= A_INTERACT ? a : (uint32_t)A_STAY);  // outside the enum = outside the contract
-            }
+        posori = pl_reg.x & 0xFFFFu;
+        held = pl_reg.y;
+        act = (active && a_raw <= A_INTERACT) ? a_raw : (uint32_t)A_STAY;  // outside the enum = outside the contract
+        if (!active) {
+            posori = 0;
+            held = kItemNone;
+        }
+    } else {
+        if (p.patch) bg_request(p, lane, bgr);
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (p.whole && !p.patch) {
+            const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;
+            for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
         }
     }
+    if (p.patch) bg_deliver(p, lane, bgr, s_tile);
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++)
         if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
     __syncthreads();
-    // Every lane takes delivery of its timestep here.  Left to its first use (inside `lane < nw`), the
-    // load stays "pending" on the other path in hipcc's bookkeeping and each later reuse of its
-    // register gets an `s_waitcnt vmcnt(0)` -- which by then waits for the wave's stores.
-    asm volatile("" : "+v"(t_loaded));
     if (nw == 0) return;
     if (ABLATED(32)) return;  // diagnostic build: launch + loads + barrier
     STAMP(1);
 
-    // ---------------- step: lane = world ----------------
-    // (Letting one wave step all worlds of the workgroup, with the other waves waiting, was
-    // tried and is no faster: this phase is ~2 us of dependent per-world logic either way.)
-    int32_t out_reward = 0, out_t = 0, out_done = 0;
-    if (lane < nw) {
-        uint32_t *obj = s_obj + lane * C;
-        uint32_t *pl = s_pl + lane * 2 * P;
-        int32_t reward = 0, t = 0;
-        bool reset_now = kInit;
-        if (!kInit) {
-            if (!ABLATED(4)) {
-                if constexpr (kP > 0)
-                    reward = transition_fixed<kP>(p, s_terrain, s_times, s_pots, obj, pl, s_act + lane * P);
-                else
-                    reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, s_act + lane * P);
-            }
-            // horizon (sim.cpp:485-489)
-            t = t_loaded + 1;
-            reset_now = (int64_t)t >= p.horizon;
+    // ---------------- step: lane = (world, player) ----------------
+    int32_t reward_world = 0, t = 0;
+    bool reset_now = kInit;
+    if (!kInit) {
+        if (!ABLATED(4)) {
+            transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
+            tick_pots(p, s_pots, s_obj, nw, lane);
         }
-        // reset (sim.cpp:441-482)
+        // horizon (sim.cpp:485-489)
+        t = t_loaded + 1;
+        reset_now = (int64_t)t >= p.horizon;
+    }
+    // reset (sim.cpp:441-482): rare, and then usually every world of the group at once
+    if (__ballot(active && reset_now) != 0ull) {
         if (reset_now) {
             t = 0;
-            for (uint32_t c = 0; c < C; c++) obj[c] = kItemNone;
-            for (uint32_t q = 0; q < P; q++) {
-                pl[2 * q] = (uint32_t)s_start[q] | (A_NORTH << 8);
-                pl[2 * q + 1] = kItemNone;
-            }
+            posori = (uint32_t)s_start[active ? q : 0u] | (A_NORTH << 8);
+            held = kItemNone;
         }
-        out_reward = reward;
-        out_t = t;
-        out_done = kInit ? 0 : (int32_t)reset_now;
-        s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;  // urgency channel (sim.cpp:79-83)
+        if (active && q == 0) s_sum[wl] = reset_now ? 1u : 0u;
+        wave_lds_sync();
+        for (uint32_t i = lane; i < ncells; i += kWave)
+            if (s_sum[__umulhi(i, p.inv_c)] != 0u) s_obj[i] = kItemNone;
+        wave_lds_sync();
     }
     STAMP(2);
-    // cell -> player map for the encode
-    for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-    wave_lds_sync();
-    if (lane < nw)
-        for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
+    // what the encode reads: player records, cell -> player map, urgency channel (sim.cpp:79-83)
+    if (active) {
+        reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+        s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+        if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+    }
     wave_lds_sync();
 
     // ---------------- store: LDS -> HBM slab, rewards, flags ----------------
@@ -721,13 +821,14 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         if (p.share && wib != 0) return;  // the siblings computed the same state
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
-        uint2 *g_pl = p.players + (size_t)w0 * P;
-        for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
-        if (lane < nw) {
-            const uint32_t world = w0 + lane;
-            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + world] = out_reward;
-            p.timestep[world] = out_t;
-            p.done[world] = out_done;
+        if (active) {
+            const uint32_t world = w0 + wl;
+            p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+            p.reward[(size_t)q * N + world] = reward_world;
+            if (q == 0) {
+                p.timestep[world] = t;
+                p.done[world] = kInit ? 0 : (int32_t)reset_now;
+            }
         }
     };
 
@@ -738,7 +839,11 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
-        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, !kInit);
+        if (p.patch)
+            observe_patch<kP>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_list, find_dynamic(p, s_obj, s_cur, s_list, nw, lane), s_tile, P,
+                              w0, nw, lane);
+        else
+            observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
         store_state();
         STAMP(15);
         STAMP_REALTIME(14);
@@ -920,8 +1025,6 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
-    const uint8_t *s_times = smem + kConstTimes;
-    const uint8_t *s_values = smem + kConstValues;
     const uint8_t *s_start = smem + kConstStart;
     const uint8_t *s_pots = smem + kConstPots;
     const uint32_t per_xcd = gridDim.x >> 3;
@@ -931,91 +1034,108 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
     uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
     uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);
-    uint8_t *s_act = wbase + p.off_act;
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(wbase + p.off_x);
+    uint32_t *s_sum = reinterpret_cast<uint32_t *>(wbase + p.off_sum);
+    uint32_t *s_blk = s_sum + p.wpw;
     uint8_t *s_cur = wbase + p.off_cur;
     uint8_t *s_flags = wbase + p.off_flags;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(wbase + p.off_list);
     uint8_t *s_tile = wbase + p.off_tile;
     const uint32_t P = kP > 0 ? (uint32_t)kP : p.P, C = p.C, N = p.num_worlds;
     const uint32_t ncells = nw * C, nplayers = nw * P;
+    const uint32_t wl = kP == 2 ? lane >> 1 : (P == 1u ? lane : __umulhi(lane, p.inv_p));
+    const uint32_t q = lane - wl * P;
+    const bool active = lane < nplayers;
+    const uint32_t world = min(w0 + wl, N - 1u);
 
+    // the lane's player and its world's clock live in registers for the whole rollout; cell objects in LDS
+    uint32_t posori = 0, held = kItemNone;
     int32_t t = 0;
     {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
-        const uint2 *g_pl = p.players + (size_t)w0 * P;
-        if (lane < nw) t = p.timestep[w0 + lane];
+        const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
+        t = p.timestep[world];
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
-        for (uint32_t i = lane; i < nplayers; i += kWave) reinterpret_cast<uint2 *>(s_pl)[i] = g_pl[i];
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (active) {
+            posori = pl_reg.x & 0xFFFFu;
+            held = pl_reg.y;
+        }
     }
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++)
         if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
     __syncthreads();
     if (nw == 0) return;
+    if (active) s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
 
-    // mrl_step_sequence with a compile-time player count: the next step's actions are requested before this
-    // step's row assembly, so their latency is not in the step-to-step chain
-    constexpr int kAhead = kP > 0 ? kP : 1;
-    int32_t ahead[kAhead];
-    const bool prefetch = kP > 0 && action_seq != nullptr;
-    if (prefetch && lane < nw)
-        for (int q = 0; q < kAhead; q++) ahead[q] = action_seq[(size_t)q * N + w0 + lane];
+    // mrl_step_sequence: the next step's action is requested before this step's encode, so its latency is
+    // not in the step-to-step chain
+    int32_t ahead = 0;
+    if (action_seq) ahead = action_seq[(size_t)(active ? q : 0u) * N + world];
     for (uint32_t k = 0; k < num_steps; k++) {
-        int32_t step_reward = 0, step_done = 0;
-        if (lane < nw) {
-            uint32_t *obj = s_obj + lane * C;
-            uint32_t *pl = s_pl + lane * 2 * P;
-            uint8_t *act = s_act + lane * P;
-            const uint32_t world = w0 + lane;
-            for (uint32_t q = 0; q < P; q++) {
-                uint32_t a;
-                if (action_seq) {  // mrl_step_sequence: step k's actions from the caller's (num_steps, P, N) array
-                    a = prefetch ? (uint32_t)ahead[kP > 0 ? q : 0] : (uint32_t)action_seq[((size_t)k * P + q) * N + world];
-                    a = a <= A_INTERACT ? a : (uint32_t)A_STAY;
-                } else {
-                    a = mrl_random_action(seed, first_step + k, world, q);
-                    if (k + 1 == num_steps) action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
-                }
-                act[q] = (uint8_t)a;
-            }
-            int32_t reward;
-            if constexpr (kP > 0)
-                reward = transition_fixed<kP>(p, s_terrain, s_times, s_pots, obj, pl, act);
-            else
-                reward = transition(p, s_terrain, s_times, s_values, s_pots, obj, pl, act);
-            t += 1;
-            const bool reset_now = (int64_t)t >= p.horizon;
+        uint32_t a;
+        if (action_seq) {  // step k's actions from the caller's (num_steps, P, N) array
+            a = (uint32_t)ahead;
+            a = a <= A_INTERACT ? a : (uint32_t)A_STAY;
+            if (k + 1 < num_steps) ahead = action_seq[((size_t)(k + 1) * P + (active ? q : 0u)) * N + world];
+        } else {
+            a = mrl_random_action(seed, first_step + k, world, q);
+            if (active && k + 1 == num_steps) action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
+        }
+        if (!active) a = A_STAY;
+        const uint32_t old_cell = wl * C + (posori & 0xFFu);
+        int32_t reward_world = 0;
+        transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, a, posori, held, reward_world);
+        tick_pots(p, s_pots, s_obj, nw, lane);
+        t += 1;
+        const bool reset_now = (int64_t)t >= p.horizon;
+        if (__ballot(active && reset_now) != 0ull) {
             if (reset_now) {
                 t = 0;
-                for (uint32_t c = 0; c < C; c++) obj[c] = kItemNone;
-                for (uint32_t q = 0; q < P; q++) {
-                    pl[2 * q] = (uint32_t)s_start[q] | (A_NORTH << 8);
-                    pl[2 * q + 1] = kItemNone;
-                }
+                posori = (uint32_t)s_start[active ? q : 0u] | (A_NORTH << 8);
+                held = kItemNone;
             }
-            step_reward = reward;
-            step_done = (int32_t)reset_now;
-            s_flags[lane] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+            if (active && q == 0) s_sum[wl] = reset_now ? 1u : 0u;
+            wave_lds_sync();
+            for (uint32_t i = lane; i < ncells; i += kWave)
+                if (s_sum[__umulhi(i, p.inv_c)] != 0u) s_obj[i] = kItemNone;
+            wave_lds_sync();
         }
-        for (uint32_t i = lane; i < (ncells + 3) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        // every lane clears its old cell before any lane marks its new one (two DS instructions, in order)
+        if (active) s_cur[old_cell] = 0xFF;
         wave_lds_sync();
-        if (lane < nw)
-            for (uint32_t q = 0; q < P; q++) s_cur[lane * C + (s_pl[(lane * P + q) * 2] & 0xFF)] = (uint8_t)q;
+        if (active) {
+            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+        }
         wave_lds_sync();
-        if (prefetch && lane < nw && k + 1 < num_steps)
-            for (int q = 0; q < kAhead; q++) ahead[q] = action_seq[((size_t)(k + 1) * P + q) * N + w0 + lane];
-        observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
-        if (lane < nw) {  // after the stream-out, like the state stores of the single step
-            for (uint32_t q = 0; q < P; q++) p.reward[(size_t)q * N + w0 + lane] = step_reward;
-            p.done[w0 + lane] = step_done;
+        if (p.patch) {
+            // the tile starts every step as the background again: the image is L1/L2-resident and lands while
+            // the dynamic cells are being listed (requested only now: 40 registers held across the transition
+            // would cost the kernel a wave per SIMD)
+            BgRegs bgr;
+            bg_request(p, lane, bgr);
+            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, nw, lane);
+            bg_deliver(p, lane, bgr, s_tile);
+            observe_patch<kP>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_list, ndyn, s_tile, P, w0, nw, lane);
+        } else {
+            observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+        }
+        if (active) {  // after the stream-out, like the state stores of the single step
+            p.reward[(size_t)q * N + world] = reward_world;
+            if (q == 0) p.done[world] = (int32_t)reset_now;
         }
         wave_lds_sync();
     }
     // state back to HBM once, after the last step
     uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
     for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
-    uint2 *g_pl = p.players + (size_t)w0 * P;
-    for (uint32_t i = lane; i < nplayers; i += kWave) g_pl[i] = reinterpret_cast<const uint2 *>(s_pl)[i];
-    if (lane < nw) p.timestep[w0 + lane] = t;
+    if (active) {
+        p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+        if (q == 0) p.timestep[world] = t;
+    }
 }
 
 // fallback for layouts without the single-pass encode: draw into the ACTION tensor, then an ordinary step
@@ -1044,6 +1164,7 @@ struct OvercookedSim final : mrl_sim {
     StepParams params{};
     uint32_t H = 0;
     uint32_t grid = 0, lds_bytes = 0;
+    bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
 
@@ -1051,10 +1172,10 @@ struct OvercookedSim final : mrl_sim {
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
-        // two-player layouts (all five standard ones) take the register-resident transition
+        // two-player layouts (all five standard ones) exchange through DPP instead of LDS
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
-        else if (a.P == 2)
+        else if (a.P == 2 && !generic)
             hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
             hipLaunchKernelGGL((mrl_overcooked_step<false, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
@@ -1068,7 +1189,7 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (params.P == 2)
+            if (params.P == 2 && !generic)
                 hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
                                    params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
             else
@@ -1089,7 +1210,7 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (params.P == 2)
+            if (params.P == 2 && !generic)
                 hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
                                    params, num_steps, 0ull, 0u, action, actions);
             else
@@ -1152,7 +1273,7 @@ struct OvercookedSim final : mrl_sim {
     }
 
     size_t action_elems() const override { return (size_t)params.P * num_worlds; }
-    const char *kernel_name() const override { return params.P == 2 ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
+    const char *kernel_name() const override { return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
 
     uint64_t bytes_per_world_step() const override
     {
@@ -1228,6 +1349,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         sim->device = gpu_id;
         sim->num_worlds = num_worlds;
         sim->H = (uint32_t)H;
+        sim->generic = mrl::debug_get("overcooked.variant", 0) == 1;
         StepParams &a = sim->params;
         const uint32_t N = num_worlds;
         a.num_worlds = N;
@@ -1268,12 +1390,16 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
             a.wpw = wpw;
             a.off_pl = up16(wpw * a.C * 4);
-            a.off_act = a.off_pl + up16(wpw * a.P * 8);
-            a.off_cur = a.off_act + up16(wpw * a.P);
+            a.off_x = a.off_pl + up16(wpw * a.P * 8);
+            a.off_sum = a.off_x + 128u * 4u;
+            a.off_cur = a.off_sum + up16(2u * wpw * 4u);
             a.off_flags = a.off_cur + up16(wpw * a.C);
-            a.off_tail = a.off_flags + up16(wpw);
+            a.off_list = a.off_flags + 64u;
+            a.off_tail = a.off_list + up16(wpw * a.C * 2u);
             const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
+            // with a background image the slab must start on a 16-byte boundary in every group
+            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.block_bytes <= (uint32_t)kBgChunksPerLane * kWave * 16u) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 a.lds_wave_stride = a.off_tile + whole_tile;
@@ -1286,8 +1412,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // worlds per wave: as many as keep >= 4096 waves in the launch, fit 40 KB of LDS per
         // workgroup (>= 4 workgroups per CU) and keep the reciprocal divisions exact
         uint32_t wpw = 64;
+        while (wpw > 1 && wpw * a.P > 64u) wpw >>= 1;  // the transition runs one lane per (world, player)
+        const uint32_t wpw_cap = wpw;
         if (const int64_t forced = mrl::debug_get("overcooked.wpw", 0)) {
-            wpw = (forced < 1 || forced > 64) ? 1u : (uint32_t)forced;
+            wpw = (forced < 1 || forced > 64) ? 1u : std::min((uint32_t)forced, wpw_cap);
         } else {
             while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
             // the single-pass encode is worth more than wider groups (measured, 32768 worlds,
@@ -1331,6 +1459,23 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.reward = sim->arena.alloc<int32_t>((size_t)N * P);
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
+        a.bg = nullptr;
+        a.bg_bytes = 0;
+        if (a.patch) {
+            // background image of one group: the static bytes of its rows, i.e. the terrain one-hot
+            // (channel 5P + t - 1 of every row of a cell with terrain t, sim.cpp:642-645), zeros elsewhere
+            a.bg_bytes = a.wpw * a.block_bytes;  // a multiple of 16 (a.patch)
+            std::vector<uint8_t> img(a.bg_bytes, 0);
+            for (uint32_t w = 0; w < a.wpw; w++)
+                for (uint32_t v = 0; v < a.P; v++)
+                    for (uint32_t c = 0; c < a.C; c++) {
+                        const uint32_t t = consts[kConstTerrain + c];
+                        if (t != T_AIR) img[(size_t)w * a.block_bytes + ((size_t)v * a.C + c) * a.F + 5 * a.P + t - 1] = 1;
+                    }
+            uint32_t *d_bg = sim->arena.alloc<uint32_t>(a.bg_bytes / 4, false);
+            MRL_HIP(hipMemcpy(d_bg, img.data(), a.bg_bytes, hipMemcpyHostToDevice));
+            a.bg = d_bg;
+        }
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
         sim->mask = sim->arena.alloc<int32_t>((size_t)N * P * 6, false);

@@ -108,6 +108,37 @@ def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
     sim.close()
 
 
+@pytest.mark.parametrize("layout,cap,n,variant", [("cramped_room", None, 4099, 1), ("counter_circuit", None, 300, 1),
+                                                   ("multiplayer_schelling", None, 257, 0), ("many_player_layout", 16, 40, 0)])
+def test_same_cell_interactions_in_player_order(layout, cap, n, variant, hip_lib, oracle_lib):
+    """The transition runs one lane per (world, player); players facing the same counter or pot must still
+    act in ascending id (the reference's rank phases, sim.cpp:259-358).  70% INTERACT and orientation
+    changes only now and then, so several players stay turned to one cell for many steps.  variant 1: the
+    two-player layouts through the any-player-count code path (LDS exchange instead of DPP)."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params(layout, 60, max_num_players=cap)
+    P, C = params["num_players"], params["height"] * params["width"]
+    F = 5 * P + 16
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    with debug_knobs({"overcooked.variant": variant}):
+        sim = make_sim(params, n)
+    assert sim.kernel_name.endswith("0>") == (variant == 1 or P != 2)
+    o = world_major(sim).view(n, P, C, F)
+    rng = np.random.default_rng(99)
+    for t in range(150):
+        acts = rng.integers(0, 5, size=(P, n)).astype(np.int32)
+        acts[rng.random((P, n)) < 0.7] = 5
+        orc.step(acts)
+        sim.step_with_actions(torch.from_numpy(acts).cuda().view(P, n, 1))
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward), f"reward, step {t}"
+        if t % 10 == 0:
+            pl, ob, ts = orc.dump()
+            assert np.array_equal(unpack_players(sim.state_players_tensor().to_torch()), pl), f"players, step {t}"
+            assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob), f"objects, step {t}"
+    sim.close()
+
+
 def test_reference_view_layout(hip_lib):
     """The (P*C, N, F) view + id tensors behave like the reference's exports:
     the reference wrapper's scatter (envs/overcooked_env.py:94-96) must give the
