@@ -98,9 +98,8 @@ struct StepParams {
                            // steps it redundantly, takes every kWavesPerBlock-th pass of its rows; wave 0 stores the state
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
-    uint32_t patch;        // single-pass encode over a background image: the group's slab starts on a 16-byte boundary
-    uint32_t bg_bytes;     // bytes of the background image (wpw worlds)
-    const uint32_t *bg;    // device: background image of one group, 16-byte padded
+    uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
+    const uint16_t *terr_pos;  // device, [rows]: offset of a row's terrain one-hot byte inside a world's block, 0xFFFF = none
     uint32_t off_pl, off_x, off_sum, off_cur, off_flags, off_list, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
@@ -563,9 +562,12 @@ __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint
     return ndyn;
 }
 
-template <int kP>
+// kRestore (persistent rollouts, where the tile outlives the step): after the stream-out the patched rows are
+// put back to their static content, so the next step again only touches what is dynamic then; s_prev remembers
+// each world's urgency flag as the tile has it.
+template <int kP, bool kRestore>
 __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
-                                              const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
+                                              const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags, uint8_t *s_prev,
                                               const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t nw,
                                               uint32_t lane)
 {
@@ -597,12 +599,20 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
             row[P + 4 * rel + w_ori] = 1;
         }
     }
-    // urgency channel (sim.cpp:79-83) of the rows that were not patched; one in ten steps at horizon 400
-    if (__ballot(lane < nw && s_flags[lane & (kWave - 1)] != 0) != 0ull) {
-        const uint32_t nrows = nw * p.rows;
-        for (uint32_t r = lane; r < nrows; r += kWave) {
-            const uint32_t l = __umulhi(r, p.inv_rows);
-            if (s_flags[l]) tile[__umul24(r, F) + F - 1u] = 1;
+    // urgency channel (sim.cpp:79-83) of the rows that were not patched: only where a world's flag differs from
+    // what the tile holds (a fresh tile holds 0); the flag changes twice per episode
+    {
+        const uint32_t mine = lane < nw ? s_flags[lane] : 0u;
+        const uint32_t had = (kRestore && lane < nw) ? s_prev[lane] : 0u;
+        if (__ballot(mine != had) != 0ull) {
+            const uint32_t nrows = nw * p.rows;
+            for (uint32_t r = lane; r < nrows; r += kWave) {
+                const uint32_t l = __umulhi(r, p.inv_rows);
+                const uint32_t f = s_flags[l];
+                if (f != (kRestore ? (uint32_t)s_prev[l] : 0u)) tile[__umul24(r, F) + F - 1u] = (uint8_t)f;
+            }
+            wave_lds_sync();
+            if (kRestore && lane < nw) s_prev[lane] = (uint8_t)mine;
         }
     }
     wave_lds_sync();
@@ -627,29 +637,59 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     }
     const uint32_t done_bytes = body << 4;
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+    if constexpr (kRestore) {
+        wave_lds_sync();
+        for (uint32_t j = lane; j < nent; j += kWave) {
+            const uint32_t k = kP == 2 ? j >> 1 : (P == 1u ? j : __umulhi(j, p.inv_p));
+            const uint32_t v = j - k * P;
+            const uint32_t i = s_list[k];
+            const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+            const uint32_t who = s_cur[i];
+            const bool occupied = who != 0xFF;
+            const uint32_t w_ori = (s_pl[(__umul24(l, P) + (occupied ? who : 0u)) * 2] >> 8) & 0xFF;
+            const uint4 t = cell_tail(p, s_terrain[c], kItemNone, kItemNone, s_flags[l]);  // the row's static tail
+            uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
+            lds_store_tail_even(row + shift, t);
+            if (occupied) {
+                const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                row[rel] = 0;
+                row[P + 4 * rel + w_ori] = 0;
+            }
+        }
+        wave_lds_sync();
+    }
 }
 
-// The background image of the group -> the tile, through registers: requested with the state loads (one
-// latency), written to LDS once they are in.  Chunks beyond the image read as zero (buffer bounds check).
-constexpr int kBgChunksPerLane = 10;  // 64 lanes x 10 x 16 bytes >= the largest single-pass tile (9400 bytes)
-struct BgRegs {
-    u32x4 c[kBgChunksPerLane];
+// The static part of the tile: zeros plus one terrain one-hot byte per row of a non-AIR cell
+// (sim.cpp:642-645).  p.terr_pos holds, per row of ONE world, the byte offset of that bit inside the
+// world's block (0xFFFF: none); a lane keeps its rows' offsets in registers and sets the byte in every
+// world of the group.  (Copying a ready-made background image from global memory instead was measured:
+// 10 KB per wave through the vector memory pipe, 64 B/clk per CU, cost ~1 us per step.)
+constexpr int kTerrPosPerLane = 4;  // rows of one world <= 256 on this path
+struct TerrPos {
+    uint32_t v[kTerrPosPerLane];
 };
-__device__ __forceinline__ void bg_request(const StepParams &p, uint32_t lane, BgRegs &r)
+__device__ __forceinline__ void terrain_request(const StepParams &p, uint32_t lane, TerrPos &r)
 {
-    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.bg), 0, (int)p.bg_bytes, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < kBgChunksPerLane; k++)
-        r.c[k] = __builtin_amdgcn_raw_buffer_load_b128(img, (int)((lane + (uint32_t)k * kWave) << 4), 0, 0);
-}
-__device__ __forceinline__ void bg_deliver(const StepParams &p, uint32_t lane, const BgRegs &r, uint8_t *tile)
-{
-    const uint32_t nchunks = p.bg_bytes >> 4;
-#pragma unroll
-    for (int k = 0; k < kBgChunksPerLane; k++) {
-        const uint32_t idx = lane + (uint32_t)k * kWave;
-        if (idx < nchunks) reinterpret_cast<u32x4 *>(tile)[idx] = r.c[k];
+    for (int k = 0; k < kTerrPosPerLane; k++) {
+        const uint32_t i = lane + (uint32_t)k * kWave;
+        r.v[k] = p.terr_pos[min(i, p.rows - 1u)];  // unconditional (see the state loads); entries >= rows are ignored below
     }
+}
+__device__ __forceinline__ void terrain_deliver(const StepParams &p, uint32_t lane, const TerrPos &r, uint8_t *tile, uint32_t nw)
+{
+#pragma unroll
+    for (int k = 0; k < kTerrPosPerLane; k++) {
+        const uint32_t i = lane + (uint32_t)k * kWave;
+        if (i < p.rows && r.v[k] != 0xFFFFu)
+            for (uint32_t l = 0; l < nw; l++) tile[__umul24(l, p.block_bytes) + r.v[k]] = 1;
+    }
+}
+__device__ __forceinline__ void tile_zero(const StepParams &p, uint32_t lane, uint8_t *tile, uint32_t nw)
+{
+    const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;  // covers any start misalignment
+    for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(tile)[k] = make_uint4(0, 0, 0, 0);
 }
 
 #ifdef MRL_DIAG
@@ -721,7 +761,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
 
     uint32_t posori = 0, held = kItemNone, act = A_STAY;
     int32_t t_loaded = 0;
-    BgRegs bgr;
+    TerrPos tpos;
     // ---------------- load: HBM slab -> LDS (straight copies) ----------------
     // All global loads of the group are issued before the first one is consumed (explicitly
     // batched: a plain copy loop waits for each load before issuing the next, which measured
@@ -741,14 +781,10 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint2 pl_reg = g_pl[active ? lane : 0u];
         const uint32_t a_raw = (uint32_t)p.actions[(size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u)];
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
-        if (p.patch) bg_request(p, lane, bgr);
-        // while the loads are in flight: the cell -> player map starts empty; without a background image the
-        // tile of the single-pass encode starts zeroed
+        if (p.patch) terrain_request(p, lane, tpos);
+        // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        if (p.whole && !p.patch) {
-            const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;  // covers any start misalignment
-            for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
-        }
+        if (p.whole) tile_zero(p, lane, s_tile, nw);
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -763,14 +799,11 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
             held = kItemNone;
         }
     } else {
-        if (p.patch) bg_request(p, lane, bgr);
+        if (p.patch) terrain_request(p, lane, tpos);
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        if (p.whole && !p.patch) {
-            const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;
-            for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
-        }
+        if (p.whole) tile_zero(p, lane, s_tile, nw);
     }
-    if (p.patch) bg_deliver(p, lane, bgr, s_tile);
+    if (p.patch) terrain_deliver(p, lane, tpos, s_tile, nw);
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++)
         if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
@@ -839,10 +872,12 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // urgency) are computed once per CELL, straight-line, and reused by the P viewers' rows.
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
-        if (p.patch)
-            observe_patch<kP>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_list, find_dynamic(p, s_obj, s_cur, s_list, nw, lane), s_tile, P,
-                              w0, nw, lane);
-        else
+        if (p.patch) {
+            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, nw, lane);
+            STAMP(4);
+            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, nw, lane);
+            STAMP(5);
+        } else
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
         store_state();
         STAMP(15);
@@ -1051,10 +1086,18 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     // the lane's player and its world's clock live in registers for the whole rollout; cell objects in LDS
     uint32_t posori = 0, held = kItemNone;
     int32_t t = 0;
+    uint8_t *s_prev = s_flags + 32;  // urgency flags as the tile holds them (wpw * 2 <= 64 players: wpw <= 32)
     {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
         t = p.timestep[world];
+        TerrPos tpos;
+        if (p.patch) {
+            terrain_request(p, lane, tpos);
+            tile_zero(p, lane, s_tile, nw);
+            terrain_deliver(p, lane, tpos, s_tile, nw);
+            if (lane < 32) s_prev[lane] = 0;
+        }
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (active) {
@@ -1112,14 +1155,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         }
         wave_lds_sync();
         if (p.patch) {
-            // the tile starts every step as the background again: the image is L1/L2-resident and lands while
-            // the dynamic cells are being listed (requested only now: 40 registers held across the transition
-            // would cost the kernel a wave per SIMD)
-            BgRegs bgr;
-            bg_request(p, lane, bgr);
+            // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
             const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, nw, lane);
-            bg_deliver(p, lane, bgr, s_tile);
-            observe_patch<kP>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_list, ndyn, s_tile, P, w0, nw, lane);
+            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, nw, lane);
         } else {
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
@@ -1399,7 +1437,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
             // with a background image the slab must start on a 16-byte boundary in every group
-            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.block_bytes <= (uint32_t)kBgChunksPerLane * kWave * 16u) ? 1u : 0u;
+            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && a.rows <= (uint32_t)kTerrPosPerLane * kWave) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 a.lds_wave_stride = a.off_tile + whole_tile;
@@ -1459,22 +1497,18 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.reward = sim->arena.alloc<int32_t>((size_t)N * P);
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
-        a.bg = nullptr;
-        a.bg_bytes = 0;
-        if (a.patch) {
-            // background image of one group: the static bytes of its rows, i.e. the terrain one-hot
-            // (channel 5P + t - 1 of every row of a cell with terrain t, sim.cpp:642-645), zeros elsewhere
-            a.bg_bytes = a.wpw * a.block_bytes;  // a multiple of 16 (a.patch)
-            std::vector<uint8_t> img(a.bg_bytes, 0);
-            for (uint32_t w = 0; w < a.wpw; w++)
-                for (uint32_t v = 0; v < a.P; v++)
-                    for (uint32_t c = 0; c < a.C; c++) {
-                        const uint32_t t = consts[kConstTerrain + c];
-                        if (t != T_AIR) img[(size_t)w * a.block_bytes + ((size_t)v * a.C + c) * a.F + 5 * a.P + t - 1] = 1;
-                    }
-            uint32_t *d_bg = sim->arena.alloc<uint32_t>(a.bg_bytes / 4, false);
-            MRL_HIP(hipMemcpy(d_bg, img.data(), a.bg_bytes, hipMemcpyHostToDevice));
-            a.bg = d_bg;
+        {
+            // per row of one world: where its terrain one-hot byte goes (channel 5P + t - 1, sim.cpp:642-645)
+            std::vector<uint16_t> pos(a.rows, 0xFFFFu);
+            for (uint32_t v = 0; v < a.P; v++)
+                for (uint32_t c = 0; c < a.C; c++) {
+                    const uint32_t t = consts[kConstTerrain + c];
+                    if (t != T_AIR && (v * a.C + c) * a.F + 5 * a.P + t - 1 < 0xFFFFu)
+                        pos[v * a.C + c] = (uint16_t)((v * a.C + c) * a.F + 5 * a.P + t - 1);
+                }
+            uint16_t *d_pos = sim->arena.alloc<uint16_t>(a.rows, false);
+            MRL_HIP(hipMemcpy(d_pos, pos.data(), a.rows * sizeof(uint16_t), hipMemcpyHostToDevice));
+            a.terr_pos = d_pos;
         }
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);

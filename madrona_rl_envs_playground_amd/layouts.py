@@ -251,3 +251,108 @@ def get_base_layout_params(layout_name, horizon, max_num_players=None):
 
     params["horizon"] = horizon
     return params
+
+
+# ---------------------------------------------------------------------------------------------
+# "Simplecooked" (overcooked2_env): the old-style layouts and their transform
+# (/root/reference/envs/overcooked2_env.py:119-258; layout files
+# /root/reference/oldercooked_ai/oldercooked_ai_py/data/layouts/*.layout).  Differences from the
+# transform above: the terrain enum puts the tomato source last (src/overcooked2_env/sim.hpp:40),
+# dish pickup is shaped (3), recipe values are NOT zeroed for unordered soups, old keys
+# (`start_order_list`, `num_items_for_soup`) are dropped.
+# ---------------------------------------------------------------------------------------------
+SIMPLECOOKED_REW_SHAPING_PARAMS = {
+    "PLACEMENT_IN_POT_REW": 3,
+    "DISH_PICKUP_REWARD": 3,
+    "SOUP_PICKUP_REWARD": 5,
+}
+
+# glyph -> TerrainT value (src/overcooked2_env/sim.hpp:40)
+SIMPLECOOKED_TERRAIN_GLYPHS = [" ", "P", "X", "O", "D", "S", "T"]
+
+
+def _old_style(grid):
+    return {"grid": grid, "start_order_list": None, "cook_time": 20, "num_items_for_soup": 3,
+            "delivery_reward": 20, "rew_shaping_params": None}
+
+
+# the reference's names for the five standard grids (overcooked_demo/overcooked_utils.py:7-14) and a tomato variant
+SIMPLECOOKED_LAYOUTS = {
+    "simple": _old_style(LAYOUTS["cramped_room"]["grid"]),
+    "unident_s": _old_style(LAYOUTS["asymmetric_advantages"]["grid"]),
+    "random1": _old_style(LAYOUTS["coordination_ring"]["grid"]),
+    "random0": _old_style(LAYOUTS["forced_coordination"]["grid"]),
+    "random3": _old_style(LAYOUTS["counter_circuit"]["grid"]),
+    "simple_tomato": _old_style("""XXPXX
+                                   T  2T
+                                   X1  O
+                                   XXDSX"""),
+}
+SIMPLECOOKED_STANDARD_LAYOUTS = ["simple", "unident_s", "random1", "random0", "random3"]
+
+
+def get_simplecooked_layout_params(layout_name, horizon, max_num_players=None):
+    """``get_base_layout_params`` of the reference's envs/overcooked2_env.py (:155-258): the keyword
+    arguments of ``SimplecookedSimulator``."""
+    if isinstance(layout_name, dict):
+        params = dict(layout_name)
+    elif layout_name.endswith(".layout"):
+        params = load_layout_file(layout_name)
+    else:
+        if layout_name not in SIMPLECOOKED_LAYOUTS:
+            raise KeyError(f"unknown layout {layout_name!r}; known: {sorted(SIMPLECOOKED_LAYOUTS)} or a path ending in .layout")
+        params = dict(SIMPLECOOKED_LAYOUTS[layout_name])
+    grid = params.pop("grid")
+    params.pop("start_order_list", None)
+    params.pop("num_items_for_soup", None)
+
+    cells = [list(row.strip()) for row in grid.split("\n")]
+    starts = [None] * 64
+    for y, row in enumerate(cells):
+        for x, glyph in enumerate(row):
+            if glyph in PLAYER_GLYPHS:
+                row[x] = " "
+                idx = PLAYER_GLYPHS.index(glyph)
+                if max_num_players is None or idx < max_num_players:
+                    starts[idx] = (x, y)
+    num_players = sum(1 for s in starts if s is not None)
+    starts = starts[:num_players]
+
+    params["height"] = len(cells)
+    params["width"] = len(cells[0])
+    params["terrain"] = [SIMPLECOOKED_TERRAIN_GLYPHS.index(g) for row in cells for g in row]
+    params["num_players"] = len(starts)
+    params["start_player_x"] = [s[0] for s in starts]
+    params["start_player_y"] = [s[1] for s in starts]
+
+    shaping = params.pop("rew_shaping_params", None) or SIMPLECOOKED_REW_SHAPING_PARAMS
+    params["placement_in_pot_rew"] = shaping["PLACEMENT_IN_POT_REW"]
+    params["dish_pickup_rew"] = shaping["DISH_PICKUP_REWARD"]
+    params["soup_pickup_rew"] = shaping["SOUP_PICKUP_REWARD"]
+
+    all_orders = params.pop("start_all_orders", None) or []
+    params.pop("start_bonus_orders", None)
+    params.pop("order_bonus", None)
+
+    times = [20] * NUM_RECIPES
+    if "onion_time" in params and "tomato_time" in params:
+        times = _per_ingredient_table(params.pop("onion_time"), params.pop("tomato_time"))
+    if "recipe_times" in params:
+        for order, t in zip(all_orders, params["recipe_times"]):
+            times[_recipe_index(order)] = t
+    if "cook_time" in params:
+        times = [params.pop("cook_time")] * NUM_RECIPES
+    params["recipe_times"] = times
+
+    values = [20] * NUM_RECIPES
+    if "onion_value" in params and "tomato_value" in params:
+        values = _per_ingredient_table(params.pop("onion_value"), params.pop("tomato_value"))
+    if "recipe_values" in params:
+        for order, v in zip(all_orders, params["recipe_values"]):
+            values[_recipe_index(order)] = v
+    if "delivery_reward" in params:
+        values = [params.pop("delivery_reward")] * NUM_RECIPES
+    params["recipe_values"] = values
+
+    params["horizon"] = horizon
+    return params

@@ -9,6 +9,7 @@
  *
  * Reference files restated (read as text, nothing copied):
  *   Overcooked: /root/reference/src/overcooked_env/sim.hpp:39-198, sim.cpp:53-659
+ *   Simplecooked: /root/reference/src/overcooked2_env/sim.hpp:12-189, sim.cpp:46-577
  *   Cartpole  : /root/reference/src/cartpole_env/sim.cpp:9-141, rng.hpp:5-40
  *   Hanabi    : /root/reference/src/hanabi_env/sim.hpp:13-140, sim.cpp:45-897, rng.hpp:5-40
  *
@@ -71,6 +72,29 @@ const int32_t *orc_overcooked_done(const orc_overcooked *s);
  *   timestep: (N) int32
  */
 void orc_overcooked_dump(const orc_overcooked *s, uint8_t *players, uint8_t *objects, int32_t *timestep);
+
+/* ------------------------------------------------------------------ */
+/* Simplecooked (overcooked2_env): same config struct, other rules     */
+/*   /root/reference/src/overcooked2_env/sim.hpp:12-14,40; sim.cpp     */
+/*   pinned against envs/overcooked2_reimplement.py through            */
+/*   tests/golden/simplecooked_*.npz                                   */
+/* ------------------------------------------------------------------ */
+
+#define ORC_SIMPLE_MAX_CELLS 100   /* MAX_SIZE (overcooked2_env/sim.hpp:12)        */
+#define ORC_SIMPLE_MAX_PLAYERS 2   /* MAX_NUM_PLAYERS (overcooked2_env/sim.hpp:13) */
+
+typedef struct orc_simplecooked orc_simplecooked;
+
+/* terrain values follow overcooked2's enum: AIR, POT, COUNTER, ONION_SOURCE, DISH_SOURCE, SERVING, TOMATO_SOURCE */
+orc_simplecooked *orc_simplecooked_create(const orc_overcooked_config *cfg, uint32_t num_worlds);
+void orc_simplecooked_destroy(orc_simplecooked *s);
+void orc_simplecooked_step(orc_simplecooked *s, const int32_t *actions, int num_threads);
+/* obs (N, P, C, F) uint8 with F = 5P + 10; reward (P, N) int32; done (N) int32 */
+const uint8_t *orc_simplecooked_obs(const orc_simplecooked *s);
+const int32_t *orc_simplecooked_reward(const orc_simplecooked *s);
+const int32_t *orc_simplecooked_done(const orc_simplecooked *s);
+/* players (N, P, 6), objects (N, C, 4) as orc_overcooked_dump; timestep (N); dishes_out (N) = WorldState.num_dishes_out */
+void orc_simplecooked_dump(const orc_simplecooked *s, uint8_t *players, uint8_t *objects, int32_t *timestep, int32_t *dishes_out);
 
 /* ------------------------------------------------------------------ */
 /* Cartpole                                                            */

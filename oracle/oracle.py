@@ -65,6 +65,15 @@ def lib():
             fn.restype, fn.argtypes = rt, [vp]
         L.orc_overcooked_dump.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8), i32p]
 
+        L.orc_simplecooked_create.restype = vp
+        L.orc_simplecooked_create.argtypes = [ctypes.POINTER(OvercookedConfig), u32]
+        L.orc_simplecooked_destroy.argtypes = [vp]
+        L.orc_simplecooked_step.argtypes = [vp, i32p, ctypes.c_int]
+        for name, rt in (("obs", ctypes.POINTER(ctypes.c_uint8)), ("reward", i32p), ("done", i32p)):
+            fn = getattr(L, "orc_simplecooked_" + name)
+            fn.restype, fn.argtypes = rt, [vp]
+        L.orc_simplecooked_dump.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8), i32p, i32p]
+
         L.orc_cartpole_create.restype = vp
         L.orc_cartpole_create.argtypes = [u32]
         L.orc_cartpole_destroy.argtypes = [vp]
@@ -152,6 +161,58 @@ class OvercookedOracle:
     def close(self):
         if self.h:
             self.L.orc_overcooked_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SimplecookedOracle:
+    """N worlds of the reference's overcooked2_env ("Simplecooked") step on the CPU.
+
+    ``params``: what the reference's ``envs/overcooked2_env.py:get_base_layout_params`` returns
+    (terrain ints in overcooked2's enum order, 16-entry recipe tables, shaping rewards, horizon)."""
+
+    def __init__(self, params, num_worlds, num_threads=1):
+        self.L = lib()
+        cfg = OvercookedConfig()
+        for k in ("height", "width", "num_players", "placement_in_pot_rew", "dish_pickup_rew",
+                  "soup_pickup_rew", "horizon"):
+            setattr(cfg, k, int(params[k]))
+        for k in ("terrain", "start_player_x", "start_player_y", "recipe_values", "recipe_times"):
+            arr = getattr(cfg, k)
+            for i, v in enumerate(params[k]):
+                arr[i] = int(v)
+        self.P, self.H, self.W = int(params["num_players"]), int(params["height"]), int(params["width"])
+        self.C, self.F, self.N = self.H * self.W, 5 * self.P + 10, int(num_worlds)
+        self.num_threads = num_threads
+        self.h = self.L.orc_simplecooked_create(ctypes.byref(cfg), self.N)
+        if not self.h:
+            raise ValueError("oracle rejected the Simplecooked config")
+        self.obs = _view(self.L.orc_simplecooked_obs(self.h), (self.N, self.P, self.C, self.F), np.uint8)
+        self.reward = _view(self.L.orc_simplecooked_reward(self.h), (self.P, self.N), np.int32)
+        self.done = _view(self.L.orc_simplecooked_done(self.h), (self.N,), np.int32)
+
+    def step(self, actions):
+        a, p = _as_i32(actions, (self.P, self.N))
+        self.L.orc_simplecooked_step(self.h, p, self.num_threads)
+
+    def dump(self):
+        pl = np.zeros((self.N, self.P, 6), np.uint8)
+        ob = np.zeros((self.N, self.C, 4), np.uint8)
+        ts = np.zeros((self.N,), np.int32)
+        dishes = np.zeros((self.N,), np.int32)
+        u8, i32 = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int32)
+        self.L.orc_simplecooked_dump(self.h, pl.ctypes.data_as(u8), ob.ctypes.data_as(u8), ts.ctypes.data_as(i32),
+                                     dishes.ctypes.data_as(i32))
+        return pl, ob, ts, dishes
+
+    def close(self):
+        if self.h:
+            self.L.orc_simplecooked_destroy(self.h)
             self.h = None
 
     def __del__(self):
