@@ -63,7 +63,7 @@ enum {
 /* element types of exported tensors (madrona::py::Tensor::ElementType subset) */
 enum { MRL_INT8 = 0, MRL_UINT8 = 1, MRL_INT32 = 2, MRL_FLOAT32 = 3, MRL_UINT32 = 4 };
 
-enum { MRL_GAME_OVERCOOKED = 1, MRL_GAME_HANABI = 2, MRL_GAME_CARTPOLE = 3 };
+enum { MRL_GAME_OVERCOOKED = 1, MRL_GAME_HANABI = 2, MRL_GAME_CARTPOLE = 3, MRL_GAME_SIMPLECOOKED = 4 };
 
 typedef struct mrl_sim mrl_sim;
 
@@ -141,6 +141,22 @@ enum {
 int mrl_overcooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
 
 /* ------------------------------------------------------------------ */
+/* Simplecooked  (reference: src/overcooked2_env, the world the trainer */
+/* and the Colab notebook use: train/env_utils.py:3)                    */
+/* ------------------------------------------------------------------ */
+
+/* replaces SimplecookedSimulator(exec_mode=CUDA, gpu_id, num_worlds, **layout)
+ * (src/overcooked2_env/bindings.cpp:15-71; Manager::Config mgr.hpp:16-35 has the fields of
+ * mrl_overcooked_config, so the struct is shared).  Differences from Overcooked that the caller sees:
+ * terrain values follow overcooked2's enum AIR, POT, COUNTER, ONION_SOURCE, DISH_SOURCE, SERVING,
+ * TOMATO_SOURCE (sim.hpp:40); height*width <= 100 and num_players <= 2 (sim.hpp:12-13); rows are
+ * F = 5P + 10 bytes (sim.hpp:121-123), so OBSERVATION is int8 (P*C, N, 5P+10) and OBS_WORLD_MAJOR
+ * (N, P, H, W, 5P+10); dish_pickup_rew is paid (sim.cpp:241-246).  Slots: the MRL_OVERCOOKED_* ids
+ * (ExportID is the same list, sim.hpp:22-37) plus STATE_DISHES_OUT int32 (N) = WorldState.num_dishes_out. */
+enum { MRL_SIMPLECOOKED_STATE_DISHES_OUT = 14 };
+int mrl_simplecooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
+
+/* ------------------------------------------------------------------ */
 /* Hanabi  (reference: src/hanabi_env; 2 players, hand of 5)            */
 /* ------------------------------------------------------------------ */
 
@@ -214,6 +230,11 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
  * later mrl_step* / mrl_rollout_random on the simulator returns MRL_ERR_DEVICE
  * (the host learns it from a word in mapped host memory: no device call, no sync). */
 int mrl_step(mrl_sim *sim, void *hip_stream);
+
+/* Launch shape of the simulator's step kernel: out = {workgroups, threads per workgroup, LDS bytes per
+ * workgroup, worlds per wavefront (0 where that is not how the game is mapped)}.  For DESIGN.md's
+ * occupancy arithmetic and the tests that guard it; no reference counterpart. */
+int mrl_launch_shape(const mrl_sim *sim, uint32_t out[4]);
 
 /* 1 if an in-kernel wait of an earlier call expired (see mrl_step), else 0.  Reads host memory only. */
 int mrl_scan_timed_out(const mrl_sim *sim);

@@ -152,6 +152,14 @@ int mrl_overcooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t
     return guarded([&] { *out = mrl::create_overcooked(cfg, gpu_id, num_worlds); });
 }
 
+int mrl_simplecooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out)
+{
+    if (!out) return MRL_ERR_INVALID;
+    *out = nullptr;
+    mrl::DeviceGuard on(gpu_id);  // the caller's current device is restored on return
+    return guarded([&] { *out = mrl::create_simplecooked(cfg, gpu_id, num_worlds); });
+}
+
 int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out)
 {
     if (!out) return MRL_ERR_INVALID;
@@ -255,6 +263,13 @@ void mrl_destroy(mrl_sim *sim)
     mrl::DeviceGuard on(sim->device);
     (void)hipDeviceSynchronize();
     delete sim;
+}
+
+int mrl_launch_shape(const mrl_sim *sim, uint32_t out[4])
+{
+    if (!sim || !out) return MRL_ERR_INVALID;
+    sim->launch_shape(out);
+    return MRL_OK;
 }
 
 int mrl_scan_timed_out(const mrl_sim *sim) { return sim && sim->scan_timed_out() ? 1 : 0; }

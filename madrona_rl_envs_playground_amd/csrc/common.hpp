@@ -172,12 +172,15 @@ struct mrl_sim {
     virtual uint64_t bytes_per_world_step() const = 0;
     // a bounded in-kernel wait expired in an earlier call: episode numbers are unspecified from there on
     virtual bool scan_timed_out() const { return false; }
+    // launch shape of the step kernel: workgroups, threads per workgroup, LDS bytes per workgroup, worlds per wave
+    virtual void launch_shape(uint32_t out[4]) const { out[0] = out[1] = out[2] = out[3] = 0; }
 };
 
 namespace mrl {
 // selects gpu_id and checks it is a gfx950 part; throws HipError
 void bind_device(int gpu_id);
 mrl_sim *create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds);
+mrl_sim *create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds);
 mrl_sim *create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds);
 mrl_sim *create_cartpole(int gpu_id, uint32_t num_worlds);
 }  // namespace mrl

@@ -541,22 +541,32 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
 // with an object on them or a player standing there: those are compacted into s_list with wave
 // ballots, and one lane per (dynamic cell, viewer) overwrites that row's 16-byte tail and sets the
 // two player bytes; rows of worlds in their last 40 steps get the urgency byte in a pass of their own.
-// the group's dynamic cells, compacted in ascending order into s_list; returns how many (wave-uniform)
+// the group's dynamic cells, compacted in ascending order into s_list; returns how many (wave-uniform).
+// All LDS reads are issued before the first ballot (a loop that reads, votes and writes per 64 cells paid
+// one LDS round trip per iteration: 0.5 us for three iterations with four waves per SIMD).
 __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint32_t *s_obj, const uint8_t *s_cur, uint16_t *s_list,
                                                  uint32_t nw, uint32_t lane)
 {
     const uint32_t ncells = nw * p.C;
+    constexpr int kBatch = 4;
     uint32_t ndyn = 0;
-    for (uint32_t i0 = 0; i0 < ncells; i0 += kWave) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < ncells;
-        const uint32_t o = s_obj[valid ? i : 0u];
-        const uint32_t who = s_cur[valid ? i : 0u];
-        const bool dyn = valid && (((o & 0xFFu) != O_NONE) | (who != 0xFFu));
-        const unsigned long long m = __ballot(dyn);
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (dyn) s_list[ndyn + before] = (uint16_t)i;
-        ndyn += (uint32_t)__popcll(m);
+    for (uint32_t i0 = 0; i0 < ncells; i0 += kBatch * kWave) {
+        uint32_t o[kBatch], who[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = min(i0 + (uint32_t)k * kWave + lane, ncells - 1u);
+            o[k] = s_obj[i];
+            who[k] = s_cur[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = i0 + (uint32_t)k * kWave + lane;
+            const bool dyn = i < ncells && (((o[k] & 0xFFu) != O_NONE) | (who[k] != 0xFFu));
+            const unsigned long long m = __ballot(dyn);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (dyn) s_list[ndyn + before] = (uint16_t)i;
+            ndyn += (uint32_t)__popcll(m);
+        }
     }
     wave_lds_sync();
     return ndyn;
@@ -1311,6 +1321,13 @@ struct OvercookedSim final : mrl_sim {
     }
 
     size_t action_elems() const override { return (size_t)params.P * num_worlds; }
+    void launch_shape(uint32_t out[4]) const override
+    {
+        out[0] = grid;
+        out[1] = kBlock;
+        out[2] = lds_bytes;
+        out[3] = params.wpw;
+    }
     const char *kernel_name() const override { return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
 
     uint64_t bytes_per_world_step() const override
@@ -1429,7 +1446,9 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.wpw = wpw;
             a.off_pl = up16(wpw * a.C * 4);
             a.off_x = a.off_pl + up16(wpw * a.P * 8);
-            a.off_sum = a.off_x + 128u * 4u;
+            // scratch of the any-player-count transition only: the two-player kernels exchange through DPP, and every
+            // byte counts -- four workgroups of a 32768-world launch must fit a CU's 160 KB together
+            a.off_sum = a.off_x + ((a.P == 2 && !sim->generic) ? 0u : 128u * 4u);
             a.off_cur = a.off_sum + up16(2u * wpw * 4u);
             a.off_flags = a.off_cur + up16(wpw * a.C);
             a.off_list = a.off_flags + 64u;

@@ -1,0 +1,719 @@
+// "Simplecooked" (the reference's overcooked2_env) world step for gfx950: the whole step fused in one
+// kernel, one wavefront per GROUP of worlds, built like overcooked.hip's single-pass path.
+//
+// Semantics follow the reference task graph
+//   /root/reference/src/overcooked2_env/sim.cpp:422-451
+// (sequential resolve_interacts :199-287 with get_pot_states :174-185 and is_dish_pickup_useful
+// :187-197, movement :289-348, pots :350-360, reset :362-420, observation rows :62-148, init :470-575)
+// with the component widths of sim.hpp:55-189.  What differs from overcooked_env and shapes this file:
+//   * terrain enum AIR, POT, COUNTER, ONION_SOURCE, DISH_SOURCE, SERVING, TOMATO_SOURCE (sim.hpp:40);
+//   * rows are F = 5P + 10 bytes; at most 2 players and 100 cells (sim.hpp:12-13), so a group's whole
+//     observation slab always fits one LDS tile: there is only the single-pass encode;
+//   * interactions are strictly sequential in player order (one graph node), a pot starts cooking by
+//     itself with its third ingredient, there is no "start cooking" interaction, and picking up a dish
+//     pays dish_pickup_rew when no dish lies on a counter (WorldState.num_dishes_out == 0) and fewer
+//     players hold a dish than there are pots that could use one;
+//   * observation channel 5P+5 is zeroed on every pass (sim.cpp:74), which wipes the TOMATO_SOURCE
+//     terrain bit that shares it: that bit is never visible; no urgency channel.
+//
+// Mapping: lane = (world of the group, player), pairs exchange through DPP (swap_pair).  Player 1's
+// interaction depends on player 0's in three ways, all carried by a few exchanged words:
+//   same counter / pot      -> player 1 runs in a second round (rank 1), exactly like overcooked.hip;
+//   dishes on counters      -> player 0's put/take of a dish changes num_dishes_out before player 1's
+//                              dish pickup is rated: the delta is exchanged;
+//   dishes in hands         -> the rating counts dishes held "now": player 0 sees player 1's hand as it
+//                              was, player 1 sees player 0's hand after its interaction.
+// With one player there is nobody to exchange with and, as in the reference's numpy twin
+// (envs/overcooked2_reimplement.py:243-245), a dish pickup is never rated useful.
+//
+// HBM layout, world-major like overcooked.hip:
+//   cell_obj [N][C] u32 name | onions<<8 | tomatoes<<16 | tick<<24;  players [N][P] 2xu32;
+//   clock [N] 2xi32 {timestep, num_dishes_out};  action [P][N] i32;  reward [P][N] i32;  done [N] i32;
+//   obs [N][P][C][F] u8, one contiguous block per world.
+#include "common.hpp"
+#include "grid_common.hpp"
+#include "random_policy.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+using namespace mrl_grid;
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+enum : uint32_t { T_AIR = 0, T_POT, T_COUNTER, T_ONION_SRC, T_DISH_SRC, T_SERVING, T_TOMATO_SRC };  // sim.hpp:40
+
+constexpr uint32_t kMaxCells = 100, kMaxPlayers = 2;  // MAX_SIZE, MAX_NUM_PLAYERS (sim.hpp:12-13)
+// constant block copied into LDS by every workgroup
+constexpr uint32_t kConstTerrain = 0;   // 112 bytes
+constexpr uint32_t kConstPots = 112;    // 112 bytes: cells holding a pot
+constexpr uint32_t kConstBytes = 224;
+
+struct SimpleParams {
+    uint32_t num_worlds;
+    uint32_t P, C, W, F;
+    uint64_t deltas;
+    uint32_t rows;         // P*C
+    uint32_t block_bytes;  // P*C*F
+    uint32_t inv_c, inv_rows;
+    uint32_t placement_rew, dish_rew, soup_pickup_rew;
+    uint32_t times_w[4], values_w[4];
+    uint32_t starts;       // start cell of player 0 | player 1 << 8
+    uint32_t wpw, num_pots;
+    uint32_t off_pl, off_cur, off_list, off_tile, lds_wave_stride;
+    int64_t horizon;
+    const uint32_t *consts;
+    const uint16_t *terr_pos;  // [rows]: offset of a row's terrain one-hot byte inside a world's block, 0xFFFF = none
+    uint32_t *cell_obj;
+    uint2 *players;
+    int2 *clock;  // {timestep, num_dishes_out}
+    const int32_t *actions;
+    int32_t *reward;
+    int32_t *done;
+    uint8_t *obs;
+    // device-side random policy (mrl_rollout_random): actions drawn in the kernel when sample != 0
+    uint32_t sample, sample_step;
+    uint64_t sample_seed;
+    int32_t *action_out;
+};
+
+// One player's interaction (sim.cpp:214-283) as straight-line selects.  `there` is the object on the faced
+// cell (meaningful for counters and pots); returns the new held item.  d_dishes: change of num_dishes_out;
+// grabbed_dish: a dish was taken from the dish source (rated by the caller, which knows the other hand).
+__device__ __forceinline__ uint32_t interact(const SimpleParams &p, uint32_t terr, uint32_t held, uint32_t &there, int32_t &reward,
+                                             int32_t &d_dishes, bool &grabbed_dish)
+{
+    const uint32_t hname = held & 0xFF, oname = there & 0xFF;
+    const int32_t tick = (int8_t)(there >> 24);
+    const int32_t need = (int32_t)lookup16(p.times_w, recipe_of(there));
+    const bool counter = terr == T_COUNTER, pot = terr == T_POT;
+    const bool empty_handed = hname == O_NONE, nothing_there = oname == O_NONE;
+    const bool put = counter & !empty_handed & nothing_there;
+    const bool take = counter & empty_handed & !nothing_there;
+    const bool plate = pot & (hname == O_DISH) & (oname == O_SOUP) & (tick >= 0) & (tick >= need);
+    const bool ingredient = pot & ((hname == O_ONION) | (hname == O_TOMATO));
+    const uint32_t soup = nothing_there ? (O_SOUP | kItemNone) : there;
+    const bool add = ingredient & !(((int8_t)(soup >> 24) >= 0) | (count_of(soup) == kMaxIngredients));
+    uint32_t soup2 = add ? soup + (hname == O_ONION ? 0x100u : 0x10000u) : soup;
+    // the third ingredient starts the pot (soup_to_be_cooked_at_location && full, sim.cpp:268-270)
+    const bool autocook = ingredient & ((int8_t)(soup2 >> 24) < 0) & (count_of(soup2) == kMaxIngredients);
+    soup2 = autocook ? (soup2 & 0x00FFFFFFu) : soup2;
+    const bool grab_onion = (terr == T_ONION_SRC) & empty_handed, grab_tomato = (terr == T_TOMATO_SRC) & empty_handed;
+    grabbed_dish = (terr == T_DISH_SRC) & empty_handed;
+    const bool serve = (terr == T_SERVING) & (hname == O_SOUP);
+    const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held));
+
+    uint32_t new_there = there;
+    new_there = ingredient ? soup2 : new_there;
+    new_there = put ? held : new_there;
+    new_there = (take | plate) ? kItemNone : new_there;
+    uint32_t new_held = held;
+    new_held = (take | plate) ? there : new_held;
+    new_held = grab_onion ? (O_ONION | kItemNone) : new_held;
+    new_held = grab_tomato ? (O_TOMATO | kItemNone) : new_held;
+    new_held = grabbed_dish ? (O_DISH | kItemNone) : new_held;
+    new_held = (put | add | serve) ? kItemNone : new_held;
+    reward += (plate ? (int32_t)p.soup_pickup_rew : 0) + (add ? (int32_t)p.placement_rew : 0) + (serve ? value : 0);
+    d_dishes = (put & (hname == O_DISH)) ? 1 : ((take & (oname == O_DISH)) ? -1 : 0);
+    there = new_there;
+    return new_held;
+}
+
+// The whole transition of a group: lane = wl * P + q.  Returns the world's reward and the new
+// num_dishes_out to every lane of the world.
+template <int kP>
+__device__ __forceinline__ void transition(const SimpleParams &p, const uint8_t *s_terrain, const uint8_t *s_pots, uint32_t *s_obj,
+                                           bool active, uint32_t wl, uint32_t q, uint32_t a, uint32_t &posori, uint32_t &held,
+                                           int32_t &dishes_out, int32_t &reward_world)
+{
+    const uint32_t C = p.C;
+    const uint32_t pos = posori & 0xFFu, ori = (posori >> 8) & 0xFFu;
+    const uint32_t tgt = pos + (uint32_t)step_of(ori, p.deltas);
+    const uint32_t terr = s_terrain[tgt];
+    const uint32_t ahead = s_terrain[pos + (uint32_t)step_of(a, p.deltas)];
+    const bool inter = active && a == A_INTERACT;
+    const bool touches = inter && (terr == T_COUNTER || terr == T_POT);
+    // get_pot_states (sim.cpp:174-185), before any interaction of this step; the lanes of a world agree
+    int32_t pot_states = 0;
+    if (active)
+        for (uint32_t k = 0; k < p.num_pots; k++) {
+            const uint32_t o = s_obj[wl * C + s_pots[k]];
+            pot_states += ((o & 0xFF) != O_NONE && ((int8_t)(o >> 24) >= 0 || count_of(o) < kMaxIngredients)) ? 1 : 0;
+        }
+    const uint32_t held_before = held;
+    uint32_t rank = 0, other_before = kItemNone;
+    if constexpr (kP == 2) {
+        const uint32_t other_key = swap_pair(touches ? tgt : 0xFFFFu);
+        other_before = swap_pair(held_before);
+        rank = (q == 1u && touches && other_key == tgt) ? 1u : 0u;
+    }
+    int32_t mine = 0, d_dishes = 0;
+    bool grabbed = false;
+    uint32_t *cell = s_obj + (touches ? wl * C + tgt : 0u);
+#pragma unroll
+    for (uint32_t r = 0; r < (uint32_t)kP; r++) {
+        const bool todo = inter && rank == r;
+        if (r > 0 && __ballot(todo) == 0ull) break;
+        if (todo) {
+            uint32_t there = touches ? *cell : kItemNone;
+            held = interact(p, terr, held, there, mine, d_dishes, grabbed);
+            if (touches) *cell = there;
+        }
+        wave_lds_sync();
+    }
+    // dish pickup shaping (sim.cpp:241-246): rated with num_dishes_out and the hands as they are when the
+    // player's turn comes: player 1 after player 0's interaction, player 0 before player 1's
+    if constexpr (kP == 2) {
+        const uint32_t other_after = swap_pair(held);
+        const int32_t other_d = (int32_t)swap_pair((uint32_t)d_dishes);
+        const uint32_t other_hand = q == 0 ? other_before : other_after;
+        const int32_t out_before_me = dishes_out + (q == 0 ? 0 : other_d);
+        const int32_t dishes_held = (other_hand & 0xFF) == O_DISH ? 1 : 0;  // the grabbing hand itself was empty
+        if (grabbed && out_before_me == 0 && dishes_held < pot_states) mine += (int32_t)p.dish_rew;
+        reward_world = mine + (int32_t)swap_pair((uint32_t)mine);
+        dishes_out += d_dishes + other_d;
+    } else {
+        reward_world = mine;  // one player: never rated useful (overcooked2_reimplement.py:243-245)
+        dishes_out += d_dishes;
+    }
+    (void)held_before;
+    // movement proposal (sim.cpp:291-309); orientation := action unless STAY / INTERACT
+    const bool moves = a != A_INTERACT;
+    const uint32_t pori = (moves && a != A_STAY) ? a : ori;
+    const uint32_t prop = (moves && ahead == T_AIR) ? pos + (uint32_t)step_of(a, p.deltas) : pos;
+    bool blocked = false;
+    if constexpr (kP == 2) {  // same target or swapped cells -> nobody moves (sim.cpp:311-348)
+        const uint32_t o = swap_pair(pos | (prop << 8));
+        const uint32_t opos = o & 0xFFu, oprop = o >> 8;
+        blocked = (prop == oprop) | ((prop == opos) & (pos == oprop));
+    }
+    posori = (blocked ? pos : prop) | (pori << 8);
+}
+
+// pots (sim.cpp:350-360), after the interactions; lane = world
+__device__ __forceinline__ void tick_pots(const SimpleParams &p, const uint8_t *s_pots, uint32_t *s_obj, uint32_t nw, uint32_t lane)
+{
+    if (lane < nw) {
+        uint32_t *obj = s_obj + lane * p.C;
+        for (uint32_t k = 0; k < p.num_pots; k++) {
+            const uint32_t c = s_pots[k];
+            const uint32_t o = obj[c];
+            const int32_t tick = (int8_t)(o >> 24);
+            if ((o & 0xFF) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o)))
+                obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+        }
+    }
+}
+
+// The 10 viewer-independent bytes of a cell's rows, row[5P .. 5P+10) (sim.cpp:62-148; terrain bytes :553-558):
+// terrain one-hot (5; channel 5 is the zeroed one), pot soup onions, cooking tick, soup not in a pot,
+// dish, onion -- the last three also for what the player standing there holds.  Returned as bytes 0-3, 4-7, 8-9.
+struct Tail10 {
+    uint32_t a, b, c;
+};
+__device__ __forceinline__ Tail10 cell_tail(uint32_t terr, uint32_t o, uint32_t h)
+{
+    const uint32_t oname = o & 0xFF, on = (o >> 8) & 0xFF, hname = h & 0xFF;
+    const int32_t tick = (int8_t)(o >> 24);
+    const bool is_soup = oname == O_SOUP, in_pot = terr == T_POT;
+    const uint32_t pot_on = (is_soup & in_pot) ? on : 0u;
+    const uint32_t pot_tick = (is_soup & in_pot & (tick >= 0)) ? (uint32_t)tick & 0xFFu : 0u;
+    const uint32_t soup = ((is_soup & !in_pot) | (hname == O_SOUP)) ? 1u : 0u;
+    const uint32_t dish = ((oname == O_DISH) | (hname == O_DISH)) ? 1u : 0u;
+    const uint32_t onion = ((oname == O_ONION) | (hname == O_ONION)) ? 1u : 0u;
+    Tail10 t;
+    t.a = (terr >= 1 && terr <= 4) ? (1u << ((terr - 1u) * 8u)) : 0u;
+    t.b = (terr == 5 ? 1u : 0u) | (pot_on << 8) | (pot_tick << 16) | (soup << 24);
+    t.c = dish | (onion << 8);
+    return t;
+}
+
+// row + 5P for P = 2 is always 2 (mod 4) in the tile (rows 20 bytes apart, worlds 40 C apart, the tile as
+// misaligned as the slab in HBM, i.e. by 0 or 8): halfword, dword, dword -- all naturally aligned.
+__device__ __forceinline__ void lds_store_tail10_p2(uint8_t *ptr, const Tail10 &t)
+{
+    const uint32_t mid = __builtin_amdgcn_alignbit(t.b, t.a, 16);  // bytes 2..5
+    const uint32_t end = __builtin_amdgcn_alignbit(t.c, t.b, 16);  // bytes 6..9
+    asm volatile("ds_write_b16 %0, %1\n\t"
+                 "ds_write_b32 %0, %2 offset:2\n\t"
+                 "ds_write_b32 %0, %3 offset:6"
+                 :
+                 : "v"(lds_addr(ptr)), "v"(t.a), "v"(mid), "v"(end)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_store_tail10_bytes(uint8_t *ptr, const Tail10 &t)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ptr[k] = (uint8_t)(t.a >> (8 * k));
+        ptr[4 + k] = (uint8_t)(t.b >> (8 * k));
+    }
+    ptr[8] = (uint8_t)t.c;
+    ptr[9] = (uint8_t)(t.c >> 8);
+}
+
+constexpr int kTerrPosPerLane = 4;  // rows of one world <= 2 * 100
+
+template <bool kInit, int kP>
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimpleParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    // constants and the group's state are requested together: one HBM/L2 latency
+    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
+    const uint8_t *s_terrain = smem + kConstTerrain;
+    const uint8_t *s_pots = smem + kConstPots;
+
+    // XCD-aware mapping: one contiguous world range per XCD (workgroups are dealt round-robin)
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
+    const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
+
+    uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);                 // [wpw][C]
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);       // [wpw][P][2]
+    uint8_t *s_cur = wbase + p.off_cur;                                    // [wpw][C] cell -> player
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(wbase + p.off_list);   // [wpw][C] dynamic cells
+    uint8_t *s_tile = wbase + p.off_tile;
+
+    constexpr uint32_t P = (uint32_t)kP;
+    const uint32_t C = p.C, N = p.num_worlds, F = p.F;
+    const uint32_t ncells = nw * C, nplayers = nw * P;
+    const uint32_t wl = kP == 2 ? lane >> 1 : lane;
+    const uint32_t q = kP == 2 ? lane & 1u : 0u;
+    const bool active = lane < nplayers;
+    const uint32_t world = min(w0 + wl, N - 1u);
+
+    uint32_t posori = 0, held = kItemNone, act = A_STAY;
+    int2 clock = make_int2(0, 0);
+    uint32_t tpos[kTerrPosPerLane];
+    // ---------------- load ----------------
+    if (!kInit) {
+        const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        constexpr int kBatch = 4;
+        uint32_t cell_reg[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = lane + k * kWave;
+            cell_reg[k] = i < ncells ? g_obj[i] : 0u;
+        }
+        // unconditional, clamped indices: behind a branch hipcc consumes a load on the spot
+        const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
+        uint32_t a_raw;
+        if (p.sample)  // uniform over the six actions (include/mrl_envs.h: mrl_rollout_random)
+            a_raw = mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, q), 6u);
+        else
+            a_raw = (uint32_t)p.actions[(size_t)q * N + world];
+        clock = p.clock[world];
+#pragma unroll
+        for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
+        // while the loads are in flight: empty cell -> player map, zeroed tile
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        for (uint32_t k = lane; k < (nw * p.block_bytes + 31u) >> 4; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = lane + k * kWave;
+            if (i < ncells) s_obj[i] = cell_reg[k];
+        }
+        for (uint32_t i = lane + kBatch * kWave; i < ncells; i += kWave) s_obj[i] = g_obj[i];
+        posori = active ? pl_reg.x & 0xFFFFu : 0u;
+        held = active ? pl_reg.y : kItemNone;
+        act = (active && a_raw <= A_INTERACT) ? a_raw : (uint32_t)A_STAY;  // outside the enum = outside the contract
+        if (p.sample && active) p.action_out[(size_t)q * N + world] = (int32_t)act;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        for (uint32_t k = lane; k < (nw * p.block_bytes + 31u) >> 4; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    }
+    // the group's slab in HBM and its image in the tile are equally misaligned, so 16-byte chunks line up
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
+    uint8_t *tile = s_tile + mis;
+    // static part of the tile: the terrain one-hot byte of every row of a non-AIR, non-tomato-source cell
+#pragma unroll
+    for (int k = 0; k < kTerrPosPerLane; k++) {
+        const uint32_t i = lane + (uint32_t)k * kWave;
+        if (i < p.rows && tpos[k] != 0xFFFFu)
+            for (uint32_t l = 0; l < nw; l++) tile[__umul24(l, p.block_bytes) + tpos[k]] = 1;
+    }
+    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+    __syncthreads();
+    if (nw == 0) return;
+
+    // ---------------- step: lane = (world, player) ----------------
+    int32_t reward_world = 0, t = 0, dishes_out = 0;
+    bool reset_now = kInit;
+    if (!kInit) {
+        dishes_out = clock.y;
+        transition<kP>(p, s_terrain, s_pots, s_obj, active, wl, q, act, posori, held, dishes_out, reward_world);
+        tick_pots(p, s_pots, s_obj, nw, lane);
+        t = clock.x + 1;  // sim.cpp:415-420
+        reset_now = (int64_t)t >= p.horizon;
+    }
+    if (__ballot(active && reset_now) != 0ull) {  // sim.cpp:362-413
+        if (reset_now) {
+            t = 0;
+            dishes_out = 0;
+            posori = ((p.starts >> (8u * q)) & 0xFFu) | (A_NORTH << 8);
+            held = kItemNone;
+        }
+        // the flags travel through the (not yet used) dynamic-cell list
+        if (active && q == 0) s_list[wl] = reset_now ? 1 : 0;
+        wave_lds_sync();
+        for (uint32_t i = lane; i < ncells; i += kWave)
+            if (s_list[__umulhi(i, p.inv_c)] != 0) s_obj[i] = kItemNone;
+        wave_lds_sync();
+    }
+    if (active) {
+        reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+        s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+    }
+    wave_lds_sync();
+
+    // ---------------- observe: only the dynamic cells (sim.cpp:62-148) ----------------
+    uint32_t ndyn = 0;
+    for (uint32_t i0 = 0; i0 < ncells; i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < ncells;
+        const uint32_t o = s_obj[valid ? i : 0u];
+        const uint32_t who = s_cur[valid ? i : 0u];
+        const bool dyn = valid && (((o & 0xFFu) != O_NONE) | (who != 0xFFu));
+        const unsigned long long m = __ballot(dyn);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (dyn) s_list[ndyn + before] = (uint16_t)i;
+        ndyn += (uint32_t)__popcll(m);
+    }
+    wave_lds_sync();
+    const uint32_t plane = __umul24(C, F), shift = 5 * P;
+    const uint32_t nent = ndyn * P;
+    for (uint32_t j = lane; j < nent; j += kWave) {
+        const uint32_t k = kP == 2 ? j >> 1 : j, v = kP == 2 ? j & 1u : 0u;
+        const uint32_t i = s_list[k];
+        const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+        const uint32_t who = s_cur[i];
+        const bool occupied = who != 0xFF;
+        const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
+        const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
+        const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
+        const Tail10 t10 = cell_tail(s_terrain[c], s_obj[i], h);
+        uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
+        if constexpr (kP == 2)
+            lds_store_tail10_p2(row + shift, t10);
+        else
+            lds_store_tail10_bytes(row + shift, t10);
+        if (occupied) {
+            const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+            row[rel] = 1;
+            row[P + 4 * rel + w_ori] = 1;
+        }
+    }
+    wave_lds_sync();
+    {   // stream the slab out: unaligned head bytes, 16-byte body as bounds-checked buffer stores, tail bytes
+        const uint32_t nbytes = nw * p.block_bytes;
+        const uint32_t head = min((16u - mis) & 15u, nbytes);
+        if (lane < head) gobs[lane] = tile[lane];
+        const uint32_t body = (nbytes - head) >> 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
+        const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs + head, 0, (int)(body << 4), 0x00020000);
+        for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+            const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+            const uint32_t last = body - 1u;
+            const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+            stream_store_rsrc(out, ka << 4, va);
+            stream_store_rsrc(out, kb << 4, vb);
+            stream_store_rsrc(out, kc << 4, vc);
+            stream_store_rsrc(out, kd << 4, vd);
+        }
+        const uint32_t done_bytes = head + (body << 4);
+        if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+    }
+
+    // ---------------- store: the LAST thing a wave does (see overcooked.hip) ----------------
+    uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+    for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
+    if (active) {
+        p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+        p.reward[(size_t)q * N + world] = reward_world;
+        if (q == 0) {
+            p.clock[world] = make_int2(t, dishes_out);
+            p.done[world] = kInit ? 0 : (int32_t)reset_now;
+        }
+    }
+}
+
+__global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * n) {
+        world_id[i] = (int32_t)(i % n);
+        row_id[i] = (int32_t)(i / n);
+    }
+}
+
+__global__ void fill_i32(int32_t *dst, int32_t value, size_t count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = value;
+}
+
+struct SimplecookedSim final : mrl_sim {
+    SimpleParams params{};
+    uint32_t H = 0, grid = 0, lds_bytes = 0;
+    int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
+    int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
+
+    void launch(bool init, const SimpleParams &a, hipStream_t stream)
+    {
+        if (init) {
+            if (a.P == 2)
+                hipLaunchKernelGGL((mrl_simplecooked_step<true, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            else
+                hipLaunchKernelGGL((mrl_simplecooked_step<true, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        } else if (a.P == 2) {
+            hipLaunchKernelGGL((mrl_simplecooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        } else {
+            hipLaunchKernelGGL((mrl_simplecooked_step<false, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        }
+        MRL_HIP(hipGetLastError());
+    }
+
+    void phase1(const int32_t *actions, hipStream_t stream) override
+    {
+        SimpleParams a = params;
+        a.actions = actions ? actions : action;
+        launch(false, a, stream);
+    }
+    void phase2(const uint32_t *, hipStream_t) override {}
+
+    // uniform random policy on the device: the draw happens in the step kernel, one launch per step
+    void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
+    {
+        SimpleParams a = params;
+        a.actions = action;
+        a.sample = 1;
+        a.sample_seed = seed;
+        a.action_out = action;
+        for (uint32_t k = 0; k < num_steps; k++) {
+            a.sample_step = first_step + k;
+            launch(false, a, stream);
+        }
+    }
+
+    void ensure_ids()
+    {
+        if (world_id) return;
+        const uint32_t P = params.P, N = num_worlds, rows = params.rows;
+        world_id = arena.alloc<int32_t>((size_t)P * N, false);
+        agent_id = arena.alloc<int32_t>((size_t)P * N, false);
+        loc_world_id = arena.alloc<int32_t>((size_t)rows * N, false);
+        loc_id = arena.alloc<int32_t>((size_t)rows * N, false);
+        const size_t a = (size_t)P * N, b = (size_t)rows * N;
+        hipLaunchKernelGGL(fill_ids, dim3((unsigned)((a + 255) / 256)), dim3(256), 0, 0, world_id, agent_id, P, N);
+        hipLaunchKernelGGL(fill_ids, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, 0, loc_world_id, loc_id, rows, N);
+        MRL_HIP(hipGetLastError());
+        MRL_HIP(hipDeviceSynchronize());
+    }
+
+    bool tensor(int slot, mrl_tensor_desc *out) override
+    {
+        const int64_t P = params.P, N = num_worlds, C = params.C, F = params.F, W = params.W;
+        switch (slot) {
+        case MRL_OVERCOOKED_DONE: *out = mrl::make_desc(params.done, MRL_INT32, device, {N}); return true;
+        case MRL_OVERCOOKED_ACTIVE_AGENT: *out = mrl::make_desc(active, MRL_INT32, device, {P, N}); return true;
+        case MRL_OVERCOOKED_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {P, N, 1}); return true;
+        case MRL_OVERCOOKED_OBSERVATION:
+            *out = mrl::make_desc(params.obs, MRL_INT8, device, {P * C, N, F}, {F, P * C * F, 1});
+            return true;
+        case MRL_OVERCOOKED_ACTION_MASK: *out = mrl::make_desc(mask, MRL_INT32, device, {P, N, 6}); return true;
+        case MRL_OVERCOOKED_REWARD: *out = mrl::make_desc(params.reward, MRL_INT32, device, {P, N}); return true;
+        case MRL_OVERCOOKED_WORLD_ID: ensure_ids(); *out = mrl::make_desc(world_id, MRL_INT32, device, {P, N}); return true;
+        case MRL_OVERCOOKED_AGENT_ID: ensure_ids(); *out = mrl::make_desc(agent_id, MRL_INT32, device, {P, N}); return true;
+        case MRL_OVERCOOKED_LOCATION_WORLD_ID:
+            ensure_ids();
+            *out = mrl::make_desc(loc_world_id, MRL_INT32, device, {P * C, N});
+            return true;
+        case MRL_OVERCOOKED_LOCATION_ID: ensure_ids(); *out = mrl::make_desc(loc_id, MRL_INT32, device, {P * C, N}); return true;
+        case MRL_OVERCOOKED_OBS_WORLD_MAJOR:
+            *out = mrl::make_desc(params.obs, MRL_INT8, device, {N, P, (int64_t)H, W, F});
+            return true;
+        case MRL_OVERCOOKED_STATE_PLAYERS: *out = mrl::make_desc(params.players, MRL_UINT8, device, {N, P, 8}); return true;
+        case MRL_OVERCOOKED_STATE_OBJECTS: *out = mrl::make_desc(params.cell_obj, MRL_UINT8, device, {N, C, 4}); return true;
+        case MRL_OVERCOOKED_STATE_TIMESTEP: *out = mrl::make_desc(params.clock, MRL_INT32, device, {N}, {2}); return true;
+        case MRL_SIMPLECOOKED_STATE_DISHES_OUT:
+            *out = mrl::make_desc(reinterpret_cast<int32_t *>(params.clock) + 1, MRL_INT32, device, {N}, {2});
+            return true;
+        default: return false;
+        }
+    }
+
+    size_t action_elems() const override { return (size_t)params.P * num_worlds; }
+    void launch_shape(uint32_t out[4]) const override
+    {
+        out[0] = grid;
+        out[1] = kBlock;
+        out[2] = lds_bytes;
+        out[3] = params.wpw;
+    }
+    const char *kernel_name() const override { return params.P == 2 ? "mrl_simplecooked_step<false, 2>" : "mrl_simplecooked_step<false, 1>"; }
+
+    uint64_t bytes_per_world_step() const override
+    {
+        // like SURVEY.md section 8d for Overcooked: actions 4P + player state r/w 2*8P + cell objects r/w 2*4C +
+        // clock {timestep, num_dishes_out} r/w 16 + obs out P*C*F + reward 4P + done 4
+        const uint64_t P = params.P, C = params.C;
+        return 4 * P + 16 * P + 8 * C + 16 + params.block_bytes + 4 * P + 4;
+    }
+};
+
+}  // namespace
+
+mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds)
+{
+    if (!cfg || !cfg->terrain || !cfg->start_player_x || !cfg->start_player_y || !cfg->recipe_values || !cfg->recipe_times) {
+        set_error("simplecooked: null config field");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    const int64_t H = cfg->height, W = cfg->width, P = cfg->num_players;
+    if (H < 3 || W < 3 || H * W > (int64_t)kMaxCells) {
+        set_error("simplecooked: height*width must be 9..100 (MAX_SIZE, src/overcooked2_env/sim.hpp:12), got %lldx%lld", (long long)H,
+                  (long long)W);
+        throw HipError{MRL_ERR_INVALID};
+    }
+    if (P < 1 || P > (int64_t)kMaxPlayers) {
+        set_error("simplecooked: num_players must be 1..2 (MAX_NUM_PLAYERS, src/overcooked2_env/sim.hpp:13), got %lld", (long long)P);
+        throw HipError{MRL_ERR_INVALID};
+    }
+    if (num_worlds == 0) {
+        set_error("simplecooked: num_worlds must be > 0");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    const int64_t C = H * W;
+    alignas(4) uint8_t consts[kConstBytes];
+    memset(consts, 0, sizeof(consts));
+    uint32_t num_pots = 0;
+    for (int64_t c = 0; c < C; c++) {
+        const int64_t t = cfg->terrain[c];
+        if (t < 0 || t > 6) {
+            set_error("simplecooked: terrain[%lld] = %lld is not a TerrainT value", (long long)c, (long long)t);
+            throw HipError{MRL_ERR_INVALID};
+        }
+        const int64_t x = c % W, y = c / W;
+        if (t == T_AIR && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) {
+            set_error("simplecooked: walkable cell on the grid border at (%lld,%lld); the step indexes neighbours without bounds checks "
+                      "(src/overcooked2_env/sim.cpp:160-172)",
+                      (long long)x, (long long)y);
+            throw HipError{MRL_ERR_INVALID};
+        }
+        consts[kConstTerrain + c] = (uint8_t)t;
+        if (t == T_POT) consts[kConstPots + num_pots++] = (uint8_t)c;
+    }
+    uint32_t starts = 0;
+    for (int64_t q = 0; q < P; q++) {
+        const int64_t x = cfg->start_player_x[q], y = cfg->start_player_y[q];
+        if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) {
+            set_error("simplecooked: start position of player %lld (%lld,%lld) is not an interior cell", (long long)q, (long long)x,
+                      (long long)y);
+            throw HipError{MRL_ERR_INVALID};
+        }
+        starts |= (uint32_t)(y * W + x) << (8 * q);
+    }
+
+    bind_device(gpu_id);
+    auto *sim = new SimplecookedSim();
+    try {
+        sim->game = MRL_GAME_SIMPLECOOKED;
+        sim->device = gpu_id;
+        sim->num_worlds = num_worlds;
+        sim->H = (uint32_t)H;
+        SimpleParams &a = sim->params;
+        const uint32_t N = num_worlds;
+        a.num_worlds = N;
+        a.P = (uint32_t)P;
+        a.C = (uint32_t)C;
+        a.W = (uint32_t)W;
+        a.F = 5 * a.P + 10;
+        a.rows = a.P * a.C;
+        a.block_bytes = a.rows * a.F;
+        a.inv_c = (uint32_t)((1ull << 32) / (uint64_t)C) + 1u;
+        a.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)a.rows) + 1u;
+        a.placement_rew = (uint8_t)cfg->placement_in_pot_rew;  // uint8 like WorldState (sim.hpp:96-98)
+        a.dish_rew = (uint8_t)cfg->dish_pickup_rew;
+        a.soup_pickup_rew = (uint8_t)cfg->soup_pickup_rew;
+        a.horizon = cfg->horizon;
+        a.num_pots = num_pots;
+        a.starts = starts;
+        a.deltas = pack_deltas(W);
+        for (int r = 0; r < 16; r++) {
+            reinterpret_cast<uint8_t *>(a.times_w)[r] = (uint8_t)cfg->recipe_times[r];
+            reinterpret_cast<uint8_t *>(a.values_w)[r] = (uint8_t)cfg->recipe_values[r];
+        }
+        // worlds per wave: as many as keep >= 4096 waves in the launch, one lane per (world, player), and a
+        // tile of at most 9400 bytes (the limit measured in overcooked.hip); powers of two
+        uint32_t wpw = 64 / a.P;
+        while (wpw > 1 && (N + wpw - 1) / wpw < 4096) wpw >>= 1;
+        while (wpw > 1 && wpw * a.block_bytes + 48u > 9400u) wpw >>= 1;
+        if (const int64_t forced = mrl::debug_get("overcooked.wpw", 0)) wpw = std::min<uint32_t>((uint32_t)std::max<int64_t>(forced, 1), 64 / a.P);
+        auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+        a.wpw = wpw;
+        a.off_pl = up16(wpw * a.C * 4);
+        a.off_cur = a.off_pl + up16(wpw * a.P * 8);
+        a.off_list = a.off_cur + up16(wpw * a.C);
+        a.off_tile = a.off_list + up16(std::max(wpw * a.C * 2u, 128u));
+        a.lds_wave_stride = a.off_tile + up16(wpw * a.block_bytes) + 48u;
+        sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
+        if (sim->lds_bytes > 65536) {
+            set_error("simplecooked: internal: %u bytes of LDS per workgroup", sim->lds_bytes);
+            throw HipError{MRL_ERR_INVALID};
+        }
+        const uint32_t waves = (N + wpw - 1) / wpw;
+        const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        sim->grid = (blocks + 7u) & ~7u;
+
+        uint32_t *d_consts = sim->arena.alloc<uint32_t>(kConstBytes / 4, false);
+        MRL_HIP(hipMemcpy(d_consts, consts, kConstBytes, hipMemcpyHostToDevice));
+        a.consts = d_consts;
+        {
+            // per row of one world: where its terrain one-hot byte goes (channel 5P + t - 1, sim.cpp:553-558); the
+            // tomato source's falls on channel 5P+5, which observationSystem zeroes on every pass (sim.cpp:74)
+            std::vector<uint16_t> pos(a.rows, 0xFFFFu);
+            for (uint32_t v = 0; v < a.P; v++)
+                for (uint32_t c = 0; c < a.C; c++) {
+                    const uint32_t t = consts[kConstTerrain + c];
+                    if (t != T_AIR && t != T_TOMATO_SRC) pos[v * a.C + c] = (uint16_t)((v * a.C + c) * a.F + 5 * a.P + t - 1);
+                }
+            uint16_t *d_pos = sim->arena.alloc<uint16_t>(a.rows, false);
+            MRL_HIP(hipMemcpy(d_pos, pos.data(), a.rows * sizeof(uint16_t), hipMemcpyHostToDevice));
+            a.terr_pos = d_pos;
+        }
+        a.cell_obj = sim->arena.alloc<uint32_t>((size_t)N * C);
+        a.players = sim->arena.alloc<uint2>((size_t)N * P);
+        a.clock = sim->arena.alloc<int2>(N);
+        a.reward = sim->arena.alloc<int32_t>((size_t)N * P);
+        a.done = sim->arena.alloc<int32_t>(N);
+        a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
+        sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
+        sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
+        sim->mask = sim->arena.alloc<int32_t>((size_t)N * P * 6, false);
+        a.actions = sim->action;
+        a.action_out = sim->action;
+        const size_t na = (size_t)N * P, nm = na * 6;
+        hipLaunchKernelGGL(fill_i32, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, 0, sim->active, 1, na);
+        hipLaunchKernelGGL(fill_i32, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, 0, sim->mask, 1, nm);
+        MRL_HIP(hipGetLastError());
+        // Sim::Sim (sim.cpp:470-575): reset state + first observation
+        sim->launch(true, a, 0);
+        MRL_HIP(hipDeviceSynchronize());
+    } catch (...) {
+        delete sim;
+        throw;
+    }
+    return sim;
+}

@@ -1,0 +1,85 @@
+"""``OvercookedMadrona`` of the "Simplecooked" world -- drop-in for /root/reference/envs/overcooked2_env.py:19-115
+(the class the reference's trainer binds, train/env_utils.py:3).
+
+Same constructor (horizon defaults to 200 here), attributes (``static_actions``, ``static_observations``,
+``static_action_mask``, ``sim`` ...) and return shapes: ``get_obs`` gives, per player, an ``(N, W, H, 5P+10)``
+int8 view plus the all-ones ``(N, 6)`` action mask the reference attaches (overcooked2_env.py:55,96-99).  As in
+``overcooked_env.py`` here, the HIP kernel writes a world-major ``(N, P, H, W, F)`` block, so no scatter runs.
+"""
+import numpy as np
+import torch
+
+from ..layouts import get_simplecooked_layout_params as get_base_layout_params  # noqa: F401  (reference name)
+from ..pantheonrl_extension.vectorenv import VectorMultiAgentEnv
+from ..pantheonrl_extension.vectorobservation import VectorObservation
+from ..simulators import ExecMode, SimplecookedSimulator
+from ..spaces import Discrete, MultiBinary
+
+NUM_ACTIONS = 6  # oldercooked_ai_py Action.ALL_ACTIONS
+
+
+class OvercookedMadrona(VectorMultiAgentEnv):
+
+    def __init__(self, layout_name, num_envs, gpu_id, debug_compile=True, use_cpu=False, use_env_cpu=False,
+                 ego_agent_idx=0, horizon=200, num_players=None):
+        self.layout_name = layout_name
+        self.base_layout_params = get_base_layout_params(layout_name, horizon, max_num_players=num_players)
+        self.width = self.base_layout_params["width"]
+        self.height = self.base_layout_params["height"]
+        self.num_players = self.base_layout_params["num_players"]
+        self.size = self.width * self.height
+        self.horizon = horizon
+
+        self.sim = SimplecookedSimulator(exec_mode=ExecMode.CPU if use_cpu else ExecMode.CUDA, gpu_id=gpu_id,
+                                         num_worlds=num_envs, debug_compile=debug_compile, **self.base_layout_params)
+
+        full_obs_size = self.width * self.height * (5 * self.num_players + 10)
+        self.obs_size = full_obs_size
+        self.state_size = full_obs_size
+
+        self.static_dones = self.sim.done_tensor().to_torch()
+        self.static_active_agents = self.sim.active_agent_tensor().to_torch().to(torch.bool)
+        self.static_actions = self.sim.action_tensor().to_torch()
+        self.static_observations = self.sim.observation_tensor().to_torch()
+        self.static_rewards = self.sim.reward_tensor().to_torch()
+        self.static_world_major_observations = self.sim.observation_world_major_tensor().to_torch()
+        self.static_scattered_active_agents = self.static_active_agents
+        self.static_scattered_rewards = self.static_rewards
+        self.static_scattered_observations = self.static_observations
+        self.static_action_mask = torch.ones((num_envs, NUM_ACTIONS), dtype=torch.bool, device=self.static_dones.device)
+
+        env_device = torch.device("cpu") if use_env_cpu else self.static_dones.device
+        super().__init__(num_envs, device=env_device, n_players=self.num_players)
+
+        self.infos = [{}] * self.num_envs
+        self.ego_ind = ego_agent_idx
+        self.observation_space = self._setup_observation_space()
+        self.share_observation_space = self.observation_space
+        self.action_space = Discrete(NUM_ACTIONS)
+        self._player_views = [self.static_world_major_observations[:, i].transpose(1, 2)
+                              for i in range(self.num_players)]
+        self.n_reset()
+
+    def _setup_observation_space(self):
+        return MultiBinary(np.array([self.width, self.height, 5 * self.num_players + 10]))
+
+    def to_torch(self, a):
+        return a.to(self.device)
+
+    def get_obs(self):
+        return [VectorObservation(self.to_torch(self.static_active_agents[i]), self.to_torch(self._player_views[i]),
+                                  action_mask=self.static_action_mask)
+                for i in range(self.n_players)]
+
+    def n_step(self, actions):
+        self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
+        self.sim.step()
+        return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
+
+    def n_reset(self):
+        """Like the reference (overcooked2_env.py:111-112) this restarts nothing: worlds restart themselves at
+        the horizon inside ``step``."""
+        return self.get_obs()
+
+    def close(self, **kwargs):
+        self.sim.close()

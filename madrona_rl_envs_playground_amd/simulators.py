@@ -2,6 +2,7 @@
 
     reference module                            class here
     build.madrona_overcooked_example_python  -> OvercookedSimulator   (src/overcooked_env/bindings.cpp:11-84)
+    build.madrona_simplecooked_example_python -> SimplecookedSimulator (src/overcooked2_env/bindings.cpp:11-84)
     build.madrona_hanabi_example_python      -> HanabiSimulator       (src/hanabi_env/bindings.cpp:8-48)
     build.madrona_cartpole_example_python    -> CartpoleSimulator     (src/cartpole_env/bindings.cpp:8-31)
 
@@ -220,6 +221,13 @@ class _Simulator:
         return int(self._L.mrl_bytes_per_world_step(self._handle))
 
     @property
+    def launch_shape(self):
+        """(workgroups, threads per workgroup, LDS bytes per workgroup, worlds per wavefront) of the step kernel."""
+        out = (ctypes.c_uint32 * 4)()
+        _lib.check(self._L.mrl_launch_shape(self._handle, ctypes.byref(out)))
+        return tuple(int(v) for v in out)
+
+    @property
     def num_worlds(self):
         return int(self._L.mrl_num_worlds(self._handle))
 
@@ -249,6 +257,8 @@ class _Simulator:
 class OvercookedSimulator(_Simulator):
     """Signature of src/overcooked_env/bindings.cpp:14-71."""
 
+    _create = "mrl_overcooked_create"
+
     def __init__(self, exec_mode, gpu_id, num_worlds, terrain, height, width, num_players, start_player_x,
                  start_player_y, placement_in_pot_rew, dish_pickup_rew, soup_pickup_rew, recipe_values, recipe_times,
                  horizon, debug_compile=True):
@@ -263,8 +273,7 @@ class OvercookedSimulator(_Simulator):
                 _lib.i64_array(recipe_values), _lib.i64_array(recipe_times)]
         cfg = _lib.OvercookedConfig(int(height), int(width), int(num_players), int(placement_in_pot_rew),
                                     int(dish_pickup_rew), int(soup_pickup_rew), int(horizon), *keep)
-        _lib.check(self._L.mrl_overcooked_create(ctypes.byref(cfg), int(gpu_id), int(num_worlds),
-                                                 ctypes.byref(self._handle)))
+        _lib.check(getattr(self._L, self._create)(ctypes.byref(cfg), int(gpu_id), int(num_worlds), ctypes.byref(self._handle)))
         self.num_players, self.height, self.width = int(num_players), int(height), int(width)
         self._action_numel = int(num_players) * int(num_worlds)
 
@@ -284,6 +293,16 @@ class OvercookedSimulator(_Simulator):
     def state_players_tensor(self): return self._tensor(11)
     def state_objects_tensor(self): return self._tensor(12)
     def state_timestep_tensor(self): return self._tensor(13)
+
+
+class SimplecookedSimulator(OvercookedSimulator):
+    """Signature of src/overcooked2_env/bindings.cpp:14-71 ("Simplecooked": the world the reference's trainer
+    uses, train/env_utils.py:3).  Same keyword arguments and tensor getters as ``OvercookedSimulator``; terrain
+    values follow overcooked2's enum (tomato source last), rows are 5P + 10 bytes, at most 2 players, 100 cells."""
+
+    _create = "mrl_simplecooked_create"
+
+    def dishes_out_tensor(self): return self._tensor(14)  # WorldState.num_dishes_out, int32 (N)
 
 
 class HanabiSimulator(_Simulator):

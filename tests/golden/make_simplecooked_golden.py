@@ -173,7 +173,7 @@ def check_layout_transform():
     for name in ("gym", "gym.spaces", "oldercooked_ai_py", "oldercooked_ai_py.data", "oldercooked_ai_py.data.layouts",
                  "oldercooked_ai_py.utils", "oldercooked_ai_py.mdp", "oldercooked_ai_py.mdp.actions",
                  "oldercooked_ai_py.mdp.overcooked_mdp", "oldercooked_ai_py.mdp.overcooked_env", "build",
-                 "build.madrona_simplecooked_example_python"):
+                 "build.madrona_simplecooked_example_python", "tensorboard", "torch.utils.tensorboard"):
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["gym"].spaces = sys.modules["gym.spaces"]
     sys.modules["gym"].Env = type("Env", (), {})
@@ -186,6 +186,7 @@ def check_layout_transform():
     sys.modules["oldercooked_ai_py.mdp.actions"].Action = type("Action", (), {"ALL_ACTIONS": list(range(6))})
     sys.modules["oldercooked_ai_py.mdp.overcooked_mdp"].OvercookedGridworld = object
     sys.modules["oldercooked_ai_py.mdp.overcooked_env"].OvercookedEnv = object
+    sys.modules["torch.utils.tensorboard"].SummaryWriter = object
     import envs.overcooked2_env as ref_env  # reference
 
     for name in layouts.SIMPLECOOKED_LAYOUTS:

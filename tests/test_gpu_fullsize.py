@@ -18,6 +18,7 @@ def test_overcooked_32768_worlds_properties(hip_lib, oracle_lib):
     n, P, H, W, F = 32768, 2, 4, 5, 26
     C = H * W
     sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+    assert sim.launch_shape == (1024, 256, sim.launch_shape[2], 8) and sim.launch_shape[2] <= 40960  # 4 workgroups per CU
     obs = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
     terrain = torch.tensor(params["terrain"], device="cuda")
     onehot = torch.zeros(C, 6, dtype=torch.int8, device="cuda")

@@ -1,0 +1,194 @@
+"""GPU parity of the Simplecooked (overcooked2_env) HIP step (through the C ABI) against
+(a) the golden vectors produced by the reference's numpy twin of that world and
+(b) the CPU oracle on seeded action streams -- bit-exact, including the internal state."""
+import glob
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+from madrona_rl_envs_playground_amd import layouts  # noqa: E402
+from madrona_rl_envs_playground_amd.simulators import ExecMode, SimplecookedSimulator  # noqa: E402
+
+
+def make_sim(params, n):
+    return SimplecookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+
+
+def unpack_players(t):
+    t = t.cpu().numpy()
+    return np.stack([t[..., 0], t[..., 1], t[..., 4], t[..., 5], t[..., 6], t[..., 7]], axis=-1)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "simplecooked_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[13:-4])
+def test_golden_vectors(path, hip_lib):
+    """Reference numpy observations / rewards / dones; the one byte per tomato-source cell where the
+    reference's C++ and numpy differ (`differs`) must be 0 as in the C++ (sim.cpp:74)."""
+    z = np.load(path)
+    params = json.loads(str(z["params"]))
+    acts, obs, rew, done, keep = z["actions"], z["obs"], z["reward"], z["done"], ~z["differs"]
+    P, C, F = params["num_players"], params["height"] * params["width"], 5 * params["num_players"] + 10
+    n = 5
+    sim = make_sim(params, n)
+    o = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    a = sim.action_tensor().to_torch()
+    r, d = sim.reward_tensor().to_torch(), sim.done_tensor().to_torch()
+    got = o.cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got[:, :, keep], np.broadcast_to(obs[0], (n, P, C, F))[:, :, keep]) and (got[:, :, ~keep] == 0).all()
+    for t in range(len(acts)):
+        a.copy_(torch.from_numpy(acts[t].astype(np.int32)).cuda()[:, None, None].expand(P, n, 1))
+        sim.step()
+        got = o.cpu().numpy().astype(np.uint8)
+        assert np.array_equal(got[:, :, keep], np.broadcast_to(obs[t + 1], (n, P, C, F))[:, :, keep]), f"obs differ at step {t}"
+        assert (got[:, :, ~keep] == 0).all()
+        assert (r.cpu().numpy() == rew[t]).all(), f"reward differs at step {t}"
+        assert (d.cpu().numpy() == done[t]).all(), f"done differs at step {t}"
+    sim.close()
+
+
+@pytest.mark.parametrize("layout,horizon,cap,n,steps,p_interact", [
+    ("simple", 200, None, 1000, 450, 0.35),
+    ("simple", 37, None, 4099, 120, 0.5),
+    ("unident_s", 60, None, 513, 150, 0.35),
+    ("random1", 50, None, 777, 150, 0.45),
+    ("random0", 50, None, 256, 120, 0.35),
+    ("random3", 50, None, 300, 120, 0.6),
+    ("simple_tomato", 80, None, 640, 200, 0.45),
+    ("simple", 30, 1, 77, 100, 0.4),                 # a single player: byte-wise row tails, no dish shaping
+    ("unident_s", 45, 1, 130, 100, 0.4),
+    ("simple", 200, None, 40000, 12, 0.35),          # 8 worlds per wave, ragged last group
+])
+def test_against_oracle(layout, horizon, cap, n, steps, p_interact, hip_lib, oracle_lib):
+    params = layouts.get_simplecooked_layout_params(layout, horizon, max_num_players=cap)
+    P, C = params["num_players"], params["height"] * params["width"]
+    F = 5 * P + 10
+    orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
+    sim = make_sim(params, n)
+    o = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    rng = np.random.default_rng(zlib.crc32(f"{layout}-{n}".encode()))
+    assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs)
+    rewards = 0
+    for t in range(steps):
+        acts = rng.integers(0, 5, size=(P, n)).astype(np.int32)
+        acts[rng.random((P, n)) < p_interact] = 5
+        orc.step(acts)
+        sim.step_with_actions(torch.from_numpy(acts).cuda().view(P, n, 1))
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward), f"reward, step {t}"
+        assert np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done), f"done, step {t}"
+        rewards += int(orc.reward[0].sum())
+        if t % 10 == 0 or t == steps - 1:
+            pl, ob, ts, dishes = orc.dump()
+            assert np.array_equal(unpack_players(sim.state_players_tensor().to_torch()), pl), f"players, step {t}"
+            assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob), f"objects, step {t}"
+            assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts), f"timestep, step {t}"
+            assert np.array_equal(sim.dishes_out_tensor().to_torch().cpu().numpy(), dishes), f"dishes out, step {t}"
+    assert rewards > 0 or steps < 50
+    sim.close()
+
+
+def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
+    """mrl_rollout_random draws the documented stream in the step kernel; mrl_step_sequence == single steps."""
+    from madrona_rl_envs_playground_amd.simulators import random_action
+    params = layouts.get_simplecooked_layout_params("random1", 23)
+    n, P = 2051, 2
+    seed = 0xABCDEF0123
+    orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
+    sim, twin = make_sim(params, n), make_sim(params, n)
+    o = sim.observation_world_major_tensor().to_torch().view(orc.obs.shape)
+    world, player = np.meshgrid(np.arange(n), np.arange(P))
+    k = 100
+    for chunk in (1, 6, 30, 2):
+        sim.rollout_random(chunk, seed=seed, first_step=k)
+        seq = []
+        for s in range(chunk):
+            acts = random_action(seed, k + s, world, player)
+            orc.step(acts)
+            seq.append(torch.from_numpy(acts).view(P, n, 1))
+        twin.step_sequence(torch.stack(seq).cuda().contiguous())
+        k += chunk
+        assert np.array_equal(sim.action_tensor().to_torch().cpu().numpy()[..., 0], acts)
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ after step {k}"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward)
+        assert np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done)
+        for name in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_players_tensor", "state_objects_tensor",
+                     "state_timestep_tensor", "dishes_out_tensor"):
+            assert torch.equal(getattr(sim, name)().to_torch(), getattr(twin, name)().to_torch()), name
+    sim.close()
+    twin.close()
+
+
+def test_env_wrapper_and_reference_views(hip_lib):
+    """envs/overcooked2_env.OvercookedMadrona: the reference's attribute names, shapes and action mask; the
+    (P*C, N, F) strided export re-indexed through the id tensors like the reference's get_obs
+    (envs/overcooked2_env.py:91-101) equals the world-major fast path."""
+    from madrona_rl_envs_playground_amd.envs.overcooked2_env import OvercookedMadrona
+    from madrona_rl_envs_playground_amd.pantheonrl_extension import RandomVectorAgent
+    n = 96
+    env = OvercookedMadrona("simple", n, 0, horizon=25)
+    P, H, W, F = 2, env.height, env.width, 20
+    assert env.observation_space.shape == (W, H, F) and env.action_space.n == 6 and env.obs_size == W * H * F
+    assert env.static_actions.shape == (P, n, 1) and env.static_observations.shape == (P * H * W, n, F)
+    env.add_partner_agent(RandomVectorAgent(lambda: torch.randint(0, 6, (n, 1), device=env.device)))
+    ob = env.reset()
+    assert ob.obs.shape == (n, W, H, F) and ob.obs.dtype == torch.int8 and ob.action_mask.shape == (n, 6) and ob.action_mask.all()
+    finished = 0
+    for _ in range(60):
+        ob, rew, done, _ = env.step(torch.randint(0, 6, (n, 1), device=env.device))
+        assert rew.shape == (n,) and done.shape == (n,)
+        finished += int(done.sum())
+    assert finished == 2 * n
+    sim = env.sim
+    loc_id, loc_world = sim.location_id_tensor().to_torch().long(), sim.location_world_id_tensor().to_torch().long()
+    scattered = torch.empty((P * H * W, n, F), dtype=torch.int8, device="cuda")
+    scattered[loc_id, loc_world, :] = env.static_observations[:, :, :F]
+    ref_style = scattered.reshape(P, H, W, n, F).transpose(1, 3)            # (P, N, W, H, F)
+    assert torch.equal(ref_style[0], ob.obs) and torch.equal(ref_style, env.static_world_major_observations.permute(1, 0, 3, 2, 4))
+    env.close()
+
+
+def test_rejects_what_the_reference_cannot_hold(hip_lib):
+    big = layouts.get_base_layout_params("many_player_layout", 100, max_num_players=2)  # 15 x 17 > MAX_SIZE
+    with pytest.raises(RuntimeError, match="100"):
+        make_sim(big, 4)
+    four = layouts.get_base_layout_params("multiplayer_schelling", 100)
+    with pytest.raises(RuntimeError, match="1..2"):
+        make_sim(four, 4)
+
+
+def test_full_shard_properties(hip_lib, oracle_lib):
+    """32768 worlds of `simple` (what the reference's trainer runs, at its per-GPU benchmark size)."""
+    horizon, steps = 90, 110
+    params = layouts.get_simplecooked_layout_params("simple", horizon)
+    n, P, C, F = 32768, 2, 20, 20
+    sim = make_sim(params, n)
+    assert sim.launch_shape[2] <= 40960  # four workgroups per CU
+    obs = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    sample = 64
+    orc = oracle_lib.SimplecookedOracle(params, 2 * sample, num_threads=4)
+    torch.manual_seed(2)
+    total = 0
+    for t in range(steps):
+        a = torch.randint(0, 8, (P, n, 1), dtype=torch.int32, device="cuda").clamp_(max=5)
+        sim.step_with_actions(a)
+        orc.step(torch.cat([a[:, :sample, 0], a[:, n - sample:, 0]], dim=1).cpu().numpy())
+        rew, done = sim.reward_tensor().to_torch(), sim.done_tensor().to_torch()
+        assert torch.equal(rew[0], rew[1]) and (rew >= 0).all()
+        total += int(rew[0].sum())
+        assert bool(done.all()) == (t == horizon - 1) and bool(done.any()) == (t == horizon - 1)
+        if t % 20 == 0:
+            assert (obs[:, :, :, 0:P].sum(dim=2) == 1).all() and (obs[:, :, :, P:5 * P].sum(dim=(2, 3)) == P).all()
+            assert torch.equal(obs[:, 0, :, 5 * P:], obs[:, 1, :, 5 * P:])
+            assert (sim.dishes_out_tensor().to_torch() >= 0).all()
+        got = torch.cat([obs[:sample], obs[n - sample:]]).cpu().numpy().astype(np.uint8)
+        assert np.array_equal(got, orc.obs), f"sampled worlds differ from the oracle at step {t}"
+    assert total > 0
+    sim.close()
