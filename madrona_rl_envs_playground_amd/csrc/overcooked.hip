@@ -795,6 +795,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.whole) tile_zero(p, lane, s_tile, nw);
+        STAMP(6);
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -817,6 +818,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++)
         if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
+    STAMP(7);
     __syncthreads();
     if (nw == 0) return;
     if (ABLATED(32)) return;  // diagnostic build: launch + loads + barrier

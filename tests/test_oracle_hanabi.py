@@ -134,3 +134,118 @@ def test_stale_buffers_of_the_waiting_agent(oracle_lib):
                 waiting = int(orc.active[0, w])  # index of the agent that is NOT active == 1 - argmax
                 waiting = 0 if orc.active[1, w] else 1
                 assert np.array_equal(orc.obs[waiting, w], before[waiting, w])
+
+
+# ---------------------------------------------------------------------------------------------
+# Hand-derived known answers for the sections the reference's checker does not look at
+# (last action, card knowledge, the deal).  Expectations below are worked out from the reference
+# text alone -- rng.hpp:7-36, drawDeck sim.cpp:45-52, the deal order sim.cpp:508-519, the hint rules
+# sim.cpp:695-788, encodeLastAction :158-289, encodeCardKnowledge :291-331 -- with inputs taken from
+# the hands section of the observation, which the reference's checker does pin.  Nothing here calls
+# or mirrors the oracle's encoder code.
+# ---------------------------------------------------------------------------------------------
+def _rng_seed(idx):
+    m = 0xFFFFFFFF
+    v0, v1, s0 = idx & m, 0, 0
+    for _ in range(8):
+        s0 = (s0 + 0x9E3779B9) & m
+        v0 = (v0 + (((((v1 << 4) & m) + 0xA341316C) & m) ^ ((v1 + s0) & m) ^ (((v1 >> 5) + 0xC8013EA4) & m))) & m
+        v1 = (v1 + (((((v0 << 4) & m) + 0xAD90777D) & m) ^ ((v0 + s0) & m) ^ (((v0 >> 5) + 0x7E95761E) & m))) & m
+    return v0
+
+
+def _deal(episode):
+    """Hands of player 0 and player 1 of a fresh full-config game: ordered 50-card deck (3/2/2/2/1 copies per
+    rank), five draws for player 0 then five for player 1, each draw = swap-with-last removal at
+    int(size * rand()) with a float32 product."""
+    deck = [5 * c + r for c in range(5) for r in range(5) for _ in range(3 if r == 0 else 1 if r == 4 else 2)]
+    v, hands = _rng_seed(episode), []
+    for _ in range(2):
+        hand = []
+        for _ in range(5):
+            v = (1664525 * v + 1013904223) & 0xFFFFFFFF
+            rnd = np.float32(v & 0xFFFFFF) / np.float32(0x1000000)
+            loc = int(np.float32(len(deck)) * rnd)
+            hand.append(deck[loc])
+            deck[loc] = deck[-1]
+            deck.pop()
+        hands.append(hand)
+    return hands
+
+
+def test_deal_known_answers(oracle_lib):
+    """World w of a fresh simulator plays episode w: both hands must be what the generator and drawDeck give."""
+    cfg, n = CONFIGS["full"], 40
+    orc = oracle_lib.HanabiOracle(cfg, n)
+    seen_by_0 = orc.obs[0, :, :125].reshape(n, 5, 25)   # player 0 sees player 1's hand (encodeHands)
+    seen_by_1 = orc.obs[1, :, :125].reshape(n, 5, 25)
+    assert (seen_by_0.sum(-1) == 1).all() and (seen_by_1.sum(-1) == 1).all()
+    for w in range(n):
+        hand0, hand1 = _deal(w)
+        assert seen_by_1[w].argmax(-1).tolist() == hand0, f"episode {w}: player 0's hand"
+        assert seen_by_0[w].argmax(-1).tolist() == hand1, f"episode {w}: player 1's hand"
+    assert len({tuple(_deal(w)[0]) for w in range(n)}) > 30  # the episodes really differ
+
+
+def test_hint_known_answers_by_hand(oracle_lib):
+    """Two hints from the initial position, checked bit by bit in the mover's fresh observation:
+    step 1: player 0 reveals the colour of player 1's card 0; step 2: player 1 reveals the rank of player 0's card 2."""
+    cfg, n = CONFIGS["full"], 48
+    orc = oracle_lib.HanabiOracle(cfg, n)
+    hand1 = orc.obs[0, :, :125].reshape(n, 5, 25).argmax(-1)   # player 1's cards (seen by player 0)
+    hand0 = orc.obs[1, :, :125].reshape(n, 5, 25).argmax(-1)   # player 0's cards (seen by player 1)
+    L, K = 253, 308                                            # offsets of the last-action / card-knowledge sections
+    colour = hand1[:, 0] // 5
+    acts = np.zeros((2, n), np.int32)
+    acts[0] = 10 + colour                                      # uid 10..14: reveal colour to the other player
+    orc.step(acts)
+    assert (orc.active[1] == 1).all() and (orc.done == 0).all()
+    o = orc.obs[1].astype(np.int64)                            # player 1 moves next: its observation is fresh
+    for w in range(n):
+        c = int(colour[w])
+        shown = [int(card // 5 == c) for card in hand1[w]]     # reveal_bitmask, card 0 first
+        want = np.zeros(55, np.int64)
+        want[1] = 1                                            # the mover sits one seat before the observer
+        want[2 + 2] = 1                                        # move type: play, discard, REVEAL COLOUR, reveal rank
+        want[6 + 0] = 1                                        # the hint went to the observer itself
+        want[8 + c] = 1                                        # colour one-hot; rank one-hot stays empty
+        want[18:23] = shown                                    # which of the target's cards were touched
+        assert o[w, L:L + 55].tolist() == want.tolist(), f"world {w}: last-action section"
+        own = o[w, K:K + 175].reshape(5, 35)
+        for j in range(5):
+            # plausibility bits all repeat ONE bit of the card's mask: bit <player loop index> (sim.cpp:311), here
+            # bit 0 = "could be colour 0 rank 0": kept by touched cards iff c == 0, by untouched cards iff c != 0
+            assert (own[j, :25] == int((c == 0) == bool(shown[j]))).all(), (w, j)
+            assert own[j, 25:30].tolist() == [int(shown[j] and v == c) for v in range(5)]
+            assert not own[j, 30:35].any()
+        other = o[w, K + 175:K + 350].reshape(5, 35)           # player 0's cards: bit 1 of an untouched mask, no knowledge
+        assert (other[:, :25] == 1).all() and not other[:, 25:].any()
+    rank = hand0[:, 2] % 5
+    acts[:] = 0
+    acts[1] = 15 + rank                                        # uid 15..19: reveal rank
+    orc.step(acts)
+    assert (orc.active[0] == 1).all()
+    o = orc.obs[0].astype(np.int64)
+    for w in range(n):
+        r, c = int(rank[w]), int(colour[w])
+        shown0 = [int(card % 5 == r) for card in hand0[w]]
+        shown1 = [int(card // 5 == c) for card in hand1[w]]
+        want = np.zeros(55, np.int64)
+        want[1] = 1
+        want[2 + 3] = 1                                        # REVEAL RANK
+        want[6 + 0] = 1
+        want[13 + r] = 1                                       # rank one-hot
+        want[18:23] = shown0
+        assert o[w, L:L + 55].tolist() == want.tolist(), f"world {w}: last-action section after the rank hint"
+        own = o[w, K:K + 175].reshape(5, 35)
+        for j in range(5):
+            assert (own[j, :25] == int((r == 0) == bool(shown0[j]))).all(), (w, j)     # bit 0: colour 0 RANK 0
+            assert not own[j, 25:30].any()
+            assert own[j, 30:35].tolist() == [int(shown0[j] and v == r) for v in range(5)]
+        other = o[w, K + 175:K + 350].reshape(5, 35)           # player 1's cards after step 1, bit 1 = colour 0 rank 1
+        for j in range(5):
+            assert (other[j, :25] == int((c == 0) == bool(shown1[j]))).all(), (w, j)
+            assert other[j, 25:30].tolist() == [int(shown1[j] and v == c) for v in range(5)]
+            assert not other[j, 30:35].any()
+    # information tokens: two hints spent (thermometer at 192..199 in the mover's observation)
+    assert (orc.obs[0][:, 192:200].sum(-1) == 6).all()
