@@ -63,7 +63,7 @@ enum {
 /* element types of exported tensors (madrona::py::Tensor::ElementType subset) */
 enum { MRL_INT8 = 0, MRL_UINT8 = 1, MRL_INT32 = 2, MRL_FLOAT32 = 3, MRL_UINT32 = 4 };
 
-enum { MRL_GAME_OVERCOOKED = 1, MRL_GAME_HANABI = 2, MRL_GAME_CARTPOLE = 3, MRL_GAME_SIMPLECOOKED = 4 };
+enum { MRL_GAME_OVERCOOKED = 1, MRL_GAME_HANABI = 2, MRL_GAME_CARTPOLE = 3, MRL_GAME_SIMPLECOOKED = 4, MRL_GAME_BALANCE = 5 };
 
 typedef struct mrl_sim mrl_sim;
 
@@ -216,6 +216,31 @@ enum {
 int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 
 /* ------------------------------------------------------------------ */
+/* Balance beam  (reference: src/balance_beam_env)                      */
+/* ------------------------------------------------------------------ */
+
+/* Slots = ExportID (src/balance_beam_env/sim.hpp:22-32); shapes as mgr.cpp:177-223:
+ *   DONE int32 (N); ACTIVE_AGENT int32 (2,N) all ones; ACTION int32 (2,N,1), values 0..3 = moves -2,-1,+1,+2;
+ *   OBSERVATION int32 (2,N,7) = own position history x[0..2], partner's x[3..5] (positions + 2), steps left;
+ *   ACTION_MASK int32 (2,N,4) all ones; REWARD float32 (2,N); WORLD_ID / AGENT_ID int32 (2,N);
+ *   RESET_COUNT uint32 (1).  The observation IS the world state (sim.cpp:99-112).  Episodes are numbered
+ *   in ascending world order like Cartpole's; mrl_step = phase 1 + phase 2. */
+enum {
+    MRL_BALANCE_DONE = 0,
+    MRL_BALANCE_ACTIVE_AGENT = 1,
+    MRL_BALANCE_ACTION = 2,
+    MRL_BALANCE_OBSERVATION = 3,
+    MRL_BALANCE_ACTION_MASK = 4,
+    MRL_BALANCE_REWARD = 5,
+    MRL_BALANCE_WORLD_ID = 6,
+    MRL_BALANCE_AGENT_ID = 7,
+    MRL_BALANCE_RESET_COUNT = 8
+};
+
+/* replaces BalanceBeamSimulator(exec_mode=CUDA, gpu_id, num_worlds) (src/balance_beam_env/bindings.cpp:10-24) */
+int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
+
+/* ------------------------------------------------------------------ */
 /* Common                                                               */
 /* ------------------------------------------------------------------ */
 
@@ -281,6 +306,7 @@ int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_ste
  * (SURVEY.md section 8f item 1): num_steps environment steps with no action tensor to fill.
  *   Overcooked  randint(high=6) per agent            scripts/overcooked_example.py:99-106
  *   Cartpole    randint(high=2)                      scripts/cartpole_example.py:53-87
+ *   Simplecooked randint(high=6) per agent; Balance beam randint(high=4) per agent (their example scripts)
  *   Hanabi      argmax(rand * mask), i.e. a uniformly random legal move of the player
  *               to move                              scripts/hanabi_example.py:53-82
  * All draws come from one counter-based hash of (seed, step index k = first_step,

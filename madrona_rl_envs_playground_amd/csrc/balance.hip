@@ -1,0 +1,341 @@
+// "Balance beam" world step for gfx950 (the reference's balance_beam_env): two agents on a line of five
+// spaces, three steps per episode; one lane per world.
+//
+// Semantics: /root/reference/src/balance_beam_env/sim.cpp:76-92 (actionSystem: moves -2, -1, +1, +2),
+// :94-97 (timeSystem), :99-112 (observationSystem: a three-deep history of own and partner positions,
+// shifted by one per step), :114-151 (checkDone: reward, out-of-range and time-out termination),
+// :45-74 (resetWorld from the episode-seeded generator, rng.hpp:5-40), graph :155-171.
+//
+// The whole world state is IN the observation the reference exports: obs.x[0] = own position + BUFFER,
+// obs.time = steps left (sim.cpp:109-111), so the kernel keeps no other per-world array.  The history
+// shift of the reference runs `for (i = 2*TIME; i > 0; i--) x[i] = x[i-1]` over an array of 2*TIME
+// entries, i.e. it also writes x[6], which is the `time` field that follows it in the struct
+// (sim.hpp:52-55) and is assigned right after; and x[TIME] is assigned right after as well.  Net effect,
+// reproduced here: x[5] = x[4], x[4] = x[3], x[2] = x[1], x[1] = x[0], x[3] = partner + BUFFER,
+// x[0] = own + BUFFER.
+//
+// Episode indices are taken in ascending world order within a step (see cartpole.hip):
+//   mrl_step_phase1  mrl_balance_step : moves, history, reward, done flag, per-workgroup finished counts
+//   mrl_step_phase2  mrl_balance_reset: exclusive prefix over the counts, re-seed finished worlds
+// and mrl_step is the two in a row.
+#include "common.hpp"
+#include "episode_scan.hpp"
+#include "random_policy.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTime = 3, kSpaces = 5, kBuffer = 2, kRow = 2 * kTime + 1;  // sim.cpp:9-13, sim.hpp:8
+
+__device__ __forceinline__ uint32_t seed_of(uint32_t episode)
+{
+    // rng.hpp:7-26
+    uint32_t v0 = episode, v1 = 0, sum = 0;
+#pragma unroll
+    for (int round = 0; round < 8; round++) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+__device__ __forceinline__ float next_uniform(uint32_t &g)
+{
+    // rng.hpp:28-36
+    g = 1664525u * g + 1013904223u;
+    return (float)(g & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+struct Row {
+    int32_t x[kRow];  // x[0..5] history, x[6] = time left
+};
+
+__device__ __forceinline__ Row load_row(const int32_t *obs, uint32_t n, uint32_t agent, uint32_t w)
+{
+    Row r;
+    const int32_t *src = obs + ((size_t)agent * n + w) * kRow;
+#pragma unroll
+    for (int k = 0; k < kRow; k++) r.x[k] = src[k];
+    return r;
+}
+
+__device__ __forceinline__ void store_row(int32_t *obs, uint32_t n, uint32_t agent, uint32_t w, const Row &r)
+{
+    int32_t *dst = obs + ((size_t)agent * n + w) * kRow;
+#pragma unroll
+    for (int k = 0; k < kRow; k++) dst[k] = r.x[k];
+}
+
+// resetWorld (sim.cpp:45-74): positions from the episode's generator, empty history
+__device__ __forceinline__ void fresh_rows(uint32_t episode, Row &r0, Row &r1)
+{
+    uint32_t g = seed_of(episode);
+    const int32_t loc0 = (int32_t)(kSpaces * next_uniform(g));
+    const int32_t loc1 = (int32_t)(kSpaces * next_uniform(g));
+#pragma unroll
+    for (int k = 0; k < 2 * kTime; k++) r0.x[k] = r1.x[k] = 0;
+    r0.x[0] = loc0 + kBuffer;
+    r0.x[kTime] = loc1 + kBuffer;
+    r1.x[0] = loc1 + kBuffer;
+    r1.x[kTime] = loc0 + kBuffer;
+    r0.x[2 * kTime] = r1.x[2 * kTime] = kTime - 1;
+}
+
+__device__ __forceinline__ int32_t move_of(int32_t choice)
+{
+    // sim.cpp:78-91; anything else leaves the agent where it is
+    return choice == 0 ? -2 : choice == 1 ? -1 : choice == 2 ? 1 : choice == 3 ? 2 : 0;
+}
+
+__device__ __forceinline__ void shift_history(Row &r, int32_t own, int32_t partner, int32_t time)
+{
+    // sim.cpp:104-111, see the header of this file
+    r.x[5] = r.x[4];
+    r.x[4] = r.x[3];
+    r.x[2] = r.x[1];
+    r.x[1] = r.x[0];
+    r.x[kTime] = partner + kBuffer;
+    r.x[0] = own + kBuffer;
+    r.x[2 * kTime] = time;
+}
+
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint32_t &block_total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votes = __ballot(flag);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(votes);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kBlock / 64; w++) {
+        const uint32_t c = s_wave[w];
+        before += w < wave ? c : 0;
+        total += c;
+    }
+    block_total = total;
+    return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+}
+
+// workgroup b owns worlds [b*chunk, (b+1)*chunk), chunk a multiple of kBlock
+__global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
+                                                           int32_t *__restrict__ obs, float *__restrict__ reward,
+                                                           int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
+                                                           int32_t *action_out, uint64_t sample_seed, uint32_t sample_step)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
+    uint32_t finished = 0;
+    for (uint32_t w = first + threadIdx.x; w < last; w += kBlock) {
+        Row r0 = load_row(obs, n, 0, w), r1 = load_row(obs, n, 1, w);
+        int32_t a0, a1;
+        if (action_out) {  // uniform over the four moves, drawn here (include/mrl_envs.h: mrl_rollout_random)
+            a0 = (int32_t)mrl::scale(mrl::policy_hash(sample_seed, sample_step, w, 0), 4u);
+            a1 = (int32_t)mrl::scale(mrl::policy_hash(sample_seed, sample_step, w, 1), 4u);
+            action_out[w] = a0;
+            action_out[(size_t)n + w] = a1;
+        } else {
+            a0 = action[w];
+            a1 = action[(size_t)n + w];
+        }
+        const int32_t loc0 = r0.x[0] - kBuffer + move_of(a0), loc1 = r1.x[0] - kBuffer + move_of(a1);
+        const int32_t time = r0.x[2 * kTime] - 1;
+        shift_history(r0, loc0, loc1, time);
+        shift_history(r1, loc1, loc0, time);
+        // checkDone (sim.cpp:114-151): double arithmetic, rounded to float once
+        const int32_t gap = loc0 > loc1 ? loc0 - loc1 : loc1 - loc0;
+        float rew = (float)(loc0 == loc1 ? 1.0 : -gap * 0.2);
+        bool over = false;
+        if (loc0 < 0 || loc0 >= kSpaces || loc1 < 0 || loc1 >= kSpaces) {
+            over = true;
+            rew = (float)(-kSpaces * (time + 1) * 0.2);
+        }
+        over |= time == 0;
+        if (!over) {  // a finished world's rows come from the reset
+            store_row(obs, n, 0, w, r0);
+            store_row(obs, n, 1, w, r1);
+        }
+        reward[w] = rew;
+        reward[(size_t)n + w] = rew;
+        done[w] = over ? 1 : 0;
+        finished += over ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) total += s_wave[w];
+        block_counts[blockIdx.x] = total;
+    }
+}
+
+// kAll: (re)initialise every world as episode world_offset + world (construction / mrl_reseed_shard)
+template <bool kAll>
+__global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t chunk, const int32_t *__restrict__ done,
+                                                            int32_t *__restrict__ obs, const uint32_t *__restrict__ block_counts,
+                                                            const uint32_t *__restrict__ episode_base, uint32_t world_offset,
+                                                            uint32_t *__restrict__ next_counter, uint32_t *__restrict__ reset_count)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_red[2 * kBlock / 64];
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
+    if (kAll) {
+        for (uint32_t w = first + threadIdx.x; w < last; w += kBlock) {
+            Row r0, r1;
+            fresh_rows(world_offset + w, r0, r1);
+            store_row(obs, n, 0, w, r0);
+            store_row(obs, n, 1, w, r1);
+        }
+        return;
+    }
+    if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
+    uint32_t grand_total = 0;
+    uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
+    const uint32_t base = *episode_base;
+    for (uint32_t w0 = first; w0 < last; w0 += kBlock) {  // uniform trip count
+        const uint32_t w = w0 + threadIdx.x;
+        const bool over = w < last && done[w] != 0;
+        uint32_t total;
+        const uint32_t rank = block_rank(over, s_wave, total);
+        if (over) {
+            Row r0, r1;
+            fresh_rows(base + running + rank, r0, r1);
+            store_row(obs, n, 0, w, r0);
+            store_row(obs, n, 1, w, r1);
+        }
+        running += total;
+        __syncthreads();  // s_wave is reused by the next round
+    }
+    if (last_block && threadIdx.x == 0) {
+        *reset_count = grand_total;
+        *next_counter = base + grand_total;
+    }
+}
+
+__global__ void fill_balance_ids(int32_t *world_id, int32_t *agent_id, int32_t *active, int32_t *mask, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * n) {
+        world_id[i] = (int32_t)(i % n);
+        agent_id[i] = (int32_t)(i / n);
+        active[i] = 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) mask[(size_t)i * 4 + k] = 1;
+    }
+}
+
+struct BalanceSim final : mrl_sim {
+    uint32_t grid = 0, chunk = 0, parity = 0;
+    int32_t *action = nullptr, *obs = nullptr, *done = nullptr, *world_id = nullptr, *agent_id = nullptr, *active = nullptr, *mask = nullptr;
+    float *reward = nullptr;
+    uint32_t *block_counts = nullptr, *counter = nullptr, *reset_count = nullptr;
+
+    void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
+    {
+        hipLaunchKernelGGL(mrl_balance_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, actions ? actions : action, obs, reward,
+                           done, block_counts, action_out, seed, sample_step);
+        MRL_HIP(hipGetLastError());
+    }
+    void phase1(const int32_t *actions, hipStream_t stream) override { launch_step(actions, nullptr, 0, 0, stream); }
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
+        hipLaunchKernelGGL((mrl_balance_reset<false>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, obs, block_counts, base,
+                           0u, counter + (parity ^ 1u), reset_count);
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
+    void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
+    {
+        for (uint32_t k = 0; k < num_steps; k++) {
+            launch_step(action, action, seed, first_step + k, stream);
+            phase2(nullptr, stream);
+        }
+    }
+    void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
+    {
+        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        MRL_HIP(hipStreamSynchronize(stream));
+    }
+    void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
+    {
+        const uint32_t *none = nullptr;
+        uint32_t *no_out = nullptr;
+        hipLaunchKernelGGL((mrl_balance_reset<true>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, obs, block_counts, none,
+                           world_offset, no_out, no_out);
+        MRL_HIP(hipGetLastError());
+        MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
+        MRL_HIP(hipMemsetAsync(reward, 0, sizeof(float) * 2 * num_worlds, stream));
+        set_episode_counter(num_worlds_total, stream);
+    }
+
+    bool tensor(int slot, mrl_tensor_desc *out) override
+    {
+        const int64_t N = num_worlds;
+        switch (slot) {
+        case MRL_BALANCE_DONE: *out = mrl::make_desc(done, MRL_INT32, device, {N}); return true;
+        case MRL_BALANCE_ACTIVE_AGENT: *out = mrl::make_desc(active, MRL_INT32, device, {2, N}); return true;
+        case MRL_BALANCE_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {2, N, 1}); return true;
+        case MRL_BALANCE_OBSERVATION: *out = mrl::make_desc(obs, MRL_INT32, device, {2, N, kRow}); return true;
+        case MRL_BALANCE_ACTION_MASK: *out = mrl::make_desc(mask, MRL_INT32, device, {2, N, 4}); return true;
+        case MRL_BALANCE_REWARD: *out = mrl::make_desc(reward, MRL_FLOAT32, device, {2, N}); return true;
+        case MRL_BALANCE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {2, N}); return true;
+        case MRL_BALANCE_AGENT_ID: *out = mrl::make_desc(agent_id, MRL_INT32, device, {2, N}); return true;
+        case MRL_BALANCE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        default: return false;
+        }
+    }
+    size_t action_elems() const override { return (size_t)2 * num_worlds; }
+    const char *kernel_name() const override { return "mrl_balance_step"; }
+    // actions 8 + both agents' rows r/w 2 * 2 * 28 + reward 8 + done 4
+    uint64_t bytes_per_world_step() const override { return 8 + 4 * kRow * 4 + 8 + 4; }
+    void launch_shape(uint32_t out[4]) const override
+    {
+        out[0] = grid;
+        out[1] = kBlock;
+        out[2] = out[3] = 0;
+    }
+};
+
+}  // namespace
+
+mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
+{
+    if (num_worlds == 0) {
+        set_error("balance: num_worlds must be > 0");
+        throw HipError{MRL_ERR_INVALID};
+    }
+    bind_device(gpu_id);
+    auto *sim = new BalanceSim();
+    try {
+        sim->game = MRL_GAME_BALANCE;
+        sim->device = gpu_id;
+        sim->num_worlds = num_worlds;
+        const uint32_t groups = (num_worlds + kBlock - 1) / kBlock;
+        const uint32_t blocks = groups < mrl::kMaxScanBlocks ? groups : mrl::kMaxScanBlocks;
+        sim->chunk = ((groups + blocks - 1) / blocks) * kBlock;
+        sim->grid = (num_worlds + sim->chunk - 1) / sim->chunk;
+        const size_t N = num_worlds;
+        sim->action = sim->arena.alloc<int32_t>(2 * N);
+        sim->obs = sim->arena.alloc<int32_t>(2 * N * kRow);
+        sim->done = sim->arena.alloc<int32_t>(N);
+        sim->reward = sim->arena.alloc<float>(2 * N);
+        sim->world_id = sim->arena.alloc<int32_t>(2 * N, false);
+        sim->agent_id = sim->arena.alloc<int32_t>(2 * N, false);
+        sim->active = sim->arena.alloc<int32_t>(2 * N, false);
+        sim->mask = sim->arena.alloc<int32_t>(2 * N * 4, false);
+        sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        sim->counter = sim->arena.alloc<uint32_t>(2);
+        sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        hipLaunchKernelGGL(fill_balance_ids, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, 0, sim->world_id, sim->agent_id, sim->active,
+                           sim->mask, num_worlds);
+        MRL_HIP(hipGetLastError());
+        sim->reseed_shard(0, num_worlds, 0);  // Sim::Sim (sim.cpp:173-202): world w starts as episode w
+        MRL_HIP(hipDeviceSynchronize());
+    } catch (...) {
+        delete sim;
+        throw;
+    }
+    return sim;
+}

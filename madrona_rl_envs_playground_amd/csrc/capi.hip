@@ -176,6 +176,14 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out)
     return guarded([&] { *out = mrl::create_cartpole(gpu_id, num_worlds); });
 }
 
+int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out)
+{
+    if (!out) return MRL_ERR_INVALID;
+    *out = nullptr;
+    mrl::DeviceGuard on(gpu_id);  // the caller's current device is restored on return
+    return guarded([&] { *out = mrl::create_balance(gpu_id, num_worlds); });
+}
+
 int mrl_step(mrl_sim *sim, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;

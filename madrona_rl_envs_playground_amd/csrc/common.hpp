@@ -183,4 +183,5 @@ mrl_sim *create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, uint32_
 mrl_sim *create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds);
 mrl_sim *create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds);
 mrl_sim *create_cartpole(int gpu_id, uint32_t num_worlds);
+mrl_sim *create_balance(int gpu_id, uint32_t num_worlds);
 }  // namespace mrl

@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, ui
 // back to one launch per step when it does.
 // ---------------------------------------------------------------------------------------------
 // test hook (mrl_debug_set "inject_scan_timeout"): raises the alarm exactly as an expired wait would
-static __global__ void raise_alarm_kernel(const Alarm alarm) { alarm.raise(); }
+__attribute__((unused)) static __global__ void raise_alarm_kernel(const Alarm alarm) { alarm.raise(); }
 
 constexpr uint32_t kMaxFusedBlocks = 4096;
 constexpr uint32_t kMaxPolls = 1u << 22;  // ~1 s of polling

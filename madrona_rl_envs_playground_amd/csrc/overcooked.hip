@@ -672,34 +672,75 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 
 // The static part of the tile: zeros plus one terrain one-hot byte per row of a non-AIR cell
 // (sim.cpp:642-645).  p.terr_pos holds, per row of ONE world, the byte offset of that bit inside the
-// world's block (0xFFFF: none); a lane keeps its rows' offsets in registers and sets the byte in every
-// world of the group.  (Copying a ready-made background image from global memory instead was measured:
-// 10 KB per wave through the vector memory pipe, 64 B/clk per CU, cost ~1 us per step.)
-constexpr int kTerrPosPerLane = 4;  // rows of one world <= 256 on this path
+// world's block (0xFFFF: none).  A lane takes rows i = lane, lane + 64, ... of the GROUP (world l = i / rows),
+// asks for its table entries together with the state loads and ends up with the tile offsets in registers.
+// (Copying a ready-made background image from global memory instead was measured: 10 KB per wave through
+// the vector memory pipe, 64 B/clk per CU, cost ~1 us per step.)
+constexpr int kTerrPosPerLane = 6;  // 64 x 6 rows >= the rows of the largest single-pass group (9400 / 26)
 struct TerrPos {
-    uint32_t v[kTerrPosPerLane];
+    uint32_t off[kTerrPosPerLane];  // byte offset in the tile, 0xFFFFFFFF = nothing to set
 };
-__device__ __forceinline__ void terrain_request(const StepParams &p, uint32_t lane, TerrPos &r)
+__device__ __forceinline__ void terrain_request(const StepParams &p, uint32_t lane, uint32_t nw, TerrPos &r)
 {
+    const uint32_t total = nw * p.rows;
 #pragma unroll
     for (int k = 0; k < kTerrPosPerLane; k++) {
         const uint32_t i = lane + (uint32_t)k * kWave;
-        r.v[k] = p.terr_pos[min(i, p.rows - 1u)];  // unconditional (see the state loads); entries >= rows are ignored below
+        const uint32_t l = __umulhi(i, p.inv_rows), row = i - __umul24(l, p.rows);
+        // unconditional load (see the state loads); rows beyond the group are masked afterwards
+        const uint32_t pos = p.terr_pos[i < total ? row : 0u];
+        r.off[k] = (i < total && pos != 0xFFFFu) ? __umul24(l, p.block_bytes) + pos : 0xFFFFFFFFu;
     }
 }
-__device__ __forceinline__ void terrain_deliver(const StepParams &p, uint32_t lane, const TerrPos &r, uint8_t *tile, uint32_t nw)
+__device__ __forceinline__ void terrain_deliver(uint32_t lane, const TerrPos &r, uint8_t *tile)
 {
 #pragma unroll
-    for (int k = 0; k < kTerrPosPerLane; k++) {
-        const uint32_t i = lane + (uint32_t)k * kWave;
-        if (i < p.rows && r.v[k] != 0xFFFFu)
-            for (uint32_t l = 0; l < nw; l++) tile[__umul24(l, p.block_bytes) + r.v[k]] = 1;
-    }
+    for (int k = 0; k < kTerrPosPerLane; k++)
+        if (r.off[k] != 0xFFFFFFFFu) tile[r.off[k]] = 1;
 }
 __device__ __forceinline__ void tile_zero(const StepParams &p, uint32_t lane, uint8_t *tile, uint32_t nw)
 {
     const uint32_t nchunks = (nw * p.block_bytes + 31u) >> 4;  // covers any start misalignment
     for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(tile)[k] = make_uint4(0, 0, 0, 0);
+}
+// Zero-fill of a 256-byte-granular tile with ds_write_addtid_b32 (LDS address = M0 + offset + 4 * lane, no address
+// register): 256 bytes per instruction at twice the rate of ds_write_b32 and 1.6x that of ds_write_b128
+// (MI355X_MICROARCH.md, LDS).  The tile is the hot LDS-write traffic of the kernel: 16 waves per CU x 8.3 KB.
+// M0 is written and restored inside each statement (hipcc reserves it and does not preserve it around asm).
+__device__ __forceinline__ void tile_zero_addtid(uint8_t *tile, uint32_t nbytes)
+{
+    const uint32_t total = (nbytes + 255u) >> 8;  // 256-byte pieces
+    uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(tile));
+    uint32_t keep;
+    const uint32_t zero = 0;
+    uint32_t done = 0;
+    for (; done + 8 <= total; done += 8, base += 2048) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %2\n\t"
+                     "ds_write_addtid_b32 %2 offset:256\n\t"
+                     "ds_write_addtid_b32 %2 offset:512\n\t"
+                     "ds_write_addtid_b32 %2 offset:768\n\t"
+                     "ds_write_addtid_b32 %2 offset:1024\n\t"
+                     "ds_write_addtid_b32 %2 offset:1280\n\t"
+                     "ds_write_addtid_b32 %2 offset:1536\n\t"
+                     "ds_write_addtid_b32 %2 offset:1792\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(zero)
+                     : "memory");
+    }
+    for (; done < total; done += 1, base += 256) {
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 0\n\t"
+                     "ds_write_addtid_b32 %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(base), "v"(zero)
+                     : "memory");
+    }
 }
 
 #ifdef MRL_DIAG
@@ -791,10 +832,13 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const uint2 pl_reg = g_pl[active ? lane : 0u];
         const uint32_t a_raw = (uint32_t)p.actions[(size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u)];
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
-        if (p.patch) terrain_request(p, lane, tpos);
+        if (p.patch) terrain_request(p, lane, nw, tpos);
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        if (p.whole) tile_zero(p, lane, s_tile, nw);
+        if (p.patch)
+            tile_zero_addtid(s_tile, nw * p.block_bytes);
+        else if (p.whole)
+            tile_zero(p, lane, s_tile, nw);
         STAMP(6);
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
@@ -810,11 +854,14 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
             held = kItemNone;
         }
     } else {
-        if (p.patch) terrain_request(p, lane, tpos);
+        if (p.patch) terrain_request(p, lane, nw, tpos);
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        if (p.whole) tile_zero(p, lane, s_tile, nw);
+        if (p.patch)
+            tile_zero_addtid(s_tile, nw * p.block_bytes);
+        else if (p.whole)
+            tile_zero(p, lane, s_tile, nw);
     }
-    if (p.patch) terrain_deliver(p, lane, tpos, s_tile, nw);
+    if (p.patch) terrain_deliver(lane, tpos, s_tile);
 #pragma unroll
     for (int j = 0; j < kConstWordsPerThread; j++)
         if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
@@ -1105,9 +1152,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         t = p.timestep[world];
         TerrPos tpos;
         if (p.patch) {
-            terrain_request(p, lane, tpos);
-            tile_zero(p, lane, s_tile, nw);
-            terrain_deliver(p, lane, tpos, s_tile, nw);
+            terrain_request(p, lane, nw, tpos);
+            tile_zero_addtid(s_tile, nw * p.block_bytes);
+            terrain_deliver(lane, tpos, s_tile);
             if (lane < 32) s_prev[lane] = 0;
         }
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
@@ -1458,10 +1505,11 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
             // with a background image the slab must start on a 16-byte boundary in every group
-            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && a.rows <= (uint32_t)kTerrPosPerLane * kWave) ? 1u : 0u;
+            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
-                a.lds_wave_stride = a.off_tile + whole_tile;
+                // with a.patch the tile is zeroed in whole 256-byte pieces (tile_zero_addtid)
+                a.lds_wave_stride = a.off_tile + (a.patch ? ((wpw * a.block_bytes + 255u) & ~255u) : whole_tile);
             } else {
                 a.off_tile = a.off_tail + wpw * a.C * 16;
                 a.lds_wave_stride = a.off_tile + tile_bytes;

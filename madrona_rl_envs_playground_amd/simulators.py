@@ -5,6 +5,7 @@
     build.madrona_simplecooked_example_python -> SimplecookedSimulator (src/overcooked2_env/bindings.cpp:11-84)
     build.madrona_hanabi_example_python      -> HanabiSimulator       (src/hanabi_env/bindings.cpp:8-48)
     build.madrona_cartpole_example_python    -> CartpoleSimulator     (src/cartpole_env/bindings.cpp:8-31)
+    build.madrona_balance_example_python     -> BalanceBeamSimulator  (src/balance_beam_env/bindings.cpp:8-34)
 
 Same constructor keywords, same method names; every ``*_tensor()`` returns an
 object whose ``to_torch()`` yields a persistent zero-copy ``torch.Tensor`` on the
@@ -346,3 +347,29 @@ class CartpoleSimulator(_Simulator):
     def world_id_tensor(self): return self._tensor(4)
     def reset_count_tensor(self): return self._tensor(5)
     def scan_timeout_tensor(self): return self._tensor(6)
+
+
+class BalanceBeamSimulator(_Simulator):
+    """Signature of src/balance_beam_env/bindings.cpp:10-24."""
+
+    def __init__(self, exec_mode, gpu_id, num_worlds, debug_compile=True):
+        super().__init__(exec_mode, gpu_id)
+        _lib.check(self._L.mrl_balance_create(int(gpu_id), int(num_worlds), ctypes.byref(self._handle)))
+        self._action_numel = 2 * int(num_worlds)
+
+    def done_tensor(self): return self._tensor(0)
+    def active_agent_tensor(self): return self._tensor(1)
+    def action_tensor(self): return self._tensor(2)
+    def observation_tensor(self): return self._tensor(3)
+    def agent_state_tensor(self): return self._tensor(3)  # alias, bindings.cpp:29
+    def action_mask_tensor(self): return self._tensor(4)
+    def reward_tensor(self): return self._tensor(5)
+    def world_id_tensor(self): return self._tensor(6)
+    def agent_id_tensor(self): return self._tensor(7)
+    def reset_count_tensor(self): return self._tensor(8)
+
+
+def random_balance_action(seed, step, world, player):
+    """Balance beam: ``(hash * 4) >> 32`` for (step index, world, player)."""
+    import numpy as np
+    return ((random_hash(seed, step, world, player).astype(np.uint64) * np.uint64(4)) >> np.uint64(32)).astype(np.int32)

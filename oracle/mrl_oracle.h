@@ -112,7 +112,24 @@ const float *orc_cartpole_reward(const orc_cartpole *s);   /* (N, 1) */
 const int32_t *orc_cartpole_done(const orc_cartpole *s);   /* (N, 1) */
 uint32_t orc_cartpole_episodes(const orc_cartpole *s);
 
-/* the episode-seeded generator both Cartpole and Hanabi use (rng.hpp:5-40) */
+/* ------------------------------------------------------------------ */
+/* Balance beam (src/balance_beam_env)                                 */
+/* ------------------------------------------------------------------ */
+
+typedef struct orc_balance orc_balance;
+
+orc_balance *orc_balance_create(uint32_t num_worlds);
+void orc_balance_destroy(orc_balance *s);
+/* actions: (2, N) int32, 0..3 = moves -2, -1, +1, +2.  Worlds are stepped in order (episode indices). */
+void orc_balance_step(orc_balance *s, const int32_t *actions);
+int32_t *orc_balance_obs(orc_balance *s);   /* (2, N, 7) int32, writable (tests plant states)   */
+int32_t *orc_balance_loc(orc_balance *s);   /* (2, N) Location.x, writable                      */
+int32_t *orc_balance_time(orc_balance *s);  /* (N) WorldTime, writable                          */
+const float *orc_balance_reward(const orc_balance *s);  /* (2, N) */
+const int32_t *orc_balance_done(const orc_balance *s);  /* (N)    */
+uint32_t orc_balance_episodes(const orc_balance *s);
+
+/* the episode-seeded generator Cartpole, Hanabi and the balance beam use (rng.hpp:5-40) */
 uint32_t orc_rng_seed(uint32_t episode_idx);
 float orc_rng_next(uint32_t *state);
 

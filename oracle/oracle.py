@@ -74,6 +74,16 @@ def lib():
             fn.restype, fn.argtypes = rt, [vp]
         L.orc_simplecooked_dump.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint8), i32p, i32p]
 
+        L.orc_balance_create.restype = vp
+        L.orc_balance_create.argtypes = [u32]
+        L.orc_balance_destroy.argtypes = [vp]
+        L.orc_balance_step.argtypes = [vp, i32p]
+        for name, rt in (("obs", i32p), ("loc", i32p), ("time", i32p), ("reward", ctypes.POINTER(ctypes.c_float)), ("done", i32p)):
+            fn = getattr(L, "orc_balance_" + name)
+            fn.restype, fn.argtypes = rt, [vp]
+        L.orc_balance_episodes.restype = u32
+        L.orc_balance_episodes.argtypes = [vp]
+
         L.orc_cartpole_create.restype = vp
         L.orc_cartpole_create.argtypes = [u32]
         L.orc_cartpole_destroy.argtypes = [vp]
@@ -213,6 +223,45 @@ class SimplecookedOracle:
     def close(self):
         if self.h:
             self.L.orc_simplecooked_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BalanceOracle:
+    """N worlds of the reference's balance-beam step on the CPU (worlds in order: episode numbering)."""
+
+    def __init__(self, num_worlds):
+        self.L = lib()
+        self.N = int(num_worlds)
+        self.h = self.L.orc_balance_create(self.N)
+        self.obs = _view(self.L.orc_balance_obs(self.h), (2, self.N, 7), np.int32)
+        self.loc = _view(self.L.orc_balance_loc(self.h), (2, self.N), np.int32)
+        self.time = _view(self.L.orc_balance_time(self.h), (self.N,), np.int32)
+        self.reward = _view(self.L.orc_balance_reward(self.h), (2, self.N), np.float32)
+        self.done = _view(self.L.orc_balance_done(self.h), (self.N,), np.int32)
+
+    def step(self, actions):
+        a, p = _as_i32(actions, (2, self.N))
+        self.L.orc_balance_step(self.h, p)
+
+    def plant(self, obs):
+        """Overwrite the state with observation rows (2, N, 7): positions and time are read back from them."""
+        self.obs[...] = obs
+        self.loc[...] = obs[:, :, 0] - 2
+        self.time[...] = obs[0, :, 6]
+
+    @property
+    def episodes(self):
+        return int(self.L.orc_balance_episodes(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.orc_balance_destroy(self.h)
             self.h = None
 
     def __del__(self):
