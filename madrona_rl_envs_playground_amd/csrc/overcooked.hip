@@ -522,15 +522,17 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     // 16-byte body as raw buffer stores over exactly the body: chunks past its end are dropped by the
     // bounds check, so the four-deep batches need no per-lane branches
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs + head, 0, (int)(body << 4), 0x00020000);
-    for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+    // (reads past the body stay inside the workgroup's LDS or return zero; their stores are dropped by the bounds check)
+    uint32_t k0 = lane;
+    for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
         const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
-        const uint32_t last = body - 1u;
-        const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+        const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
         stream_store_rsrc(out, ka << 4, va);
         stream_store_rsrc(out, kb << 4, vb);
         stream_store_rsrc(out, kc << 4, vc);
         stream_store_rsrc(out, kd << 4, vd);
     }
+    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc(out, k0 << 4, src[k0]);
     const uint32_t done_bytes = head + (body << 4);
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
 }
@@ -560,6 +562,7 @@ __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint
         }
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
+            if (i0 + (uint32_t)k * kWave >= ncells) break;  // wave-uniform
             const uint32_t i = i0 + (uint32_t)k * kWave + lane;
             const bool dyn = i < ncells && (((o[k] & 0xFFu) != O_NONE) | (who[k] != 0xFFu));
             const unsigned long long m = __ballot(dyn);
@@ -586,11 +589,9 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     if (p.ablate & 8u) return;  // diagnostic build: no encode at all
 #endif
     const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
-    const uint32_t nent = ndyn * P;
-    for (uint32_t j = lane; j < nent; j += kWave) {
-        const uint32_t k = kP == 2 ? j >> 1 : (P == 1u ? j : __umulhi(j, p.inv_p));
-        const uint32_t v = j - k * P;
-        const uint32_t i = s_list[k];
+    // lane = dynamic cell; its 16-byte tail is worked out once and dropped into the rows of all P viewers
+    for (uint32_t j = lane; j < ndyn; j += kWave) {
+        const uint32_t i = s_list[j];
         const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
         const uint32_t terr = s_terrain[c];
         const uint32_t o = s_obj[i];
@@ -601,12 +602,20 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
         const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
         const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
         const uint4 t = cell_tail(p, terr, o, h, urgent);
-        uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
-        lds_store_tail_even(row + shift, t);  // this path is only taken for even P: every tail is 2-byte aligned
-        if (occupied) {
-            const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
-            row[rel] = 1;
-            row[P + 4 * rel + w_ori] = 1;
+        uint8_t *row0 = tile + __umul24(l, p.block_bytes) + __umul24(c, F);
+        auto viewer_row = [&](uint32_t v, uint8_t *row) {
+            lds_store_tail_even(row + shift, t);  // this path is only taken for even P: every tail is 2-byte aligned
+            if (occupied) {
+                const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                row[rel] = 1;
+                row[P + 4 * rel + w_ori] = 1;
+            }
+        };
+        if constexpr (kP == 2) {
+            viewer_row(0, row0);
+            viewer_row(1, row0 + plane);
+        } else {
+            for (uint32_t v = 0; v < P; v++) viewer_row(v, row0 + __umul24(v, plane));
         }
     }
     // urgency channel (sim.cpp:79-83) of the rows that were not patched: only where a world's flag differs from
@@ -636,34 +645,42 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     const uint32_t body = nbytes >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(tile);
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs, 0, (int)(body << 4), 0x00020000);
-    for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+    // (reads past the body stay inside the workgroup's LDS or return zero; their stores are dropped by the bounds check)
+    uint32_t k0 = lane;
+    for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
         const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
-        const uint32_t last = body - 1u;
-        const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+        const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
         stream_store_rsrc(out, ka << 4, va);
         stream_store_rsrc(out, kb << 4, vb);
         stream_store_rsrc(out, kc << 4, vc);
         stream_store_rsrc(out, kd << 4, vd);
     }
+    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc(out, k0 << 4, src[k0]);
     const uint32_t done_bytes = body << 4;
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
     if constexpr (kRestore) {
         wave_lds_sync();
-        for (uint32_t j = lane; j < nent; j += kWave) {
-            const uint32_t k = kP == 2 ? j >> 1 : (P == 1u ? j : __umulhi(j, p.inv_p));
-            const uint32_t v = j - k * P;
-            const uint32_t i = s_list[k];
+        for (uint32_t j = lane; j < ndyn; j += kWave) {
+            const uint32_t i = s_list[j];
             const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
             const uint32_t who = s_cur[i];
             const bool occupied = who != 0xFF;
             const uint32_t w_ori = (s_pl[(__umul24(l, P) + (occupied ? who : 0u)) * 2] >> 8) & 0xFF;
             const uint4 t = cell_tail(p, s_terrain[c], kItemNone, kItemNone, s_flags[l]);  // the row's static tail
-            uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
-            lds_store_tail_even(row + shift, t);
-            if (occupied) {
-                const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
-                row[rel] = 0;
-                row[P + 4 * rel + w_ori] = 0;
+            uint8_t *row0 = tile + __umul24(l, p.block_bytes) + __umul24(c, F);
+            auto viewer_row = [&](uint32_t v, uint8_t *row) {
+                lds_store_tail_even(row + shift, t);
+                if (occupied) {
+                    const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                    row[rel] = 0;
+                    row[P + 4 * rel + w_ori] = 0;
+                }
+            };
+            if constexpr (kP == 2) {
+                viewer_row(0, row0);
+                viewer_row(1, row0 + plane);
+            } else {
+                for (uint32_t v = 0; v < P; v++) viewer_row(v, row0 + __umul24(v, plane));
             }
         }
         wave_lds_sync();
@@ -676,7 +693,7 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 // asks for its table entries together with the state loads and ends up with the tile offsets in registers.
 // (Copying a ready-made background image from global memory instead was measured: 10 KB per wave through
 // the vector memory pipe, 64 B/clk per CU, cost ~1 us per step.)
-constexpr int kTerrPosPerLane = 6;  // 64 x 6 rows >= the rows of the largest single-pass group (9400 / 26)
+constexpr int kTerrPosPerLane = 10;  // 64 x 10 rows: room for 16-world groups of the smallest layout
 struct TerrPos {
     uint32_t off[kTerrPosPerLane];  // byte offset in the tile, 0xFFFFFFFF = nothing to set
 };
@@ -1542,6 +1559,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_rollout<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_rollout<0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
         }
         // Few worlds of a large layout leave most of the GPU idle at one wave per world: the four waves of a

@@ -6,7 +6,7 @@ installed here).  Only what callers of the env API read is provided:
 import numpy as np
 
 try:  # pragma: no cover - not installed in the build image
-    from gym.spaces import Box, Discrete, MultiBinary  # noqa: F401
+    from gym.spaces import Box, Discrete, MultiBinary, MultiDiscrete  # noqa: F401
 except Exception:  # noqa: BLE001
 
     class Space:
@@ -39,6 +39,18 @@ except Exception:  # noqa: BLE001
 
         def __repr__(self):
             return f"MultiBinary({self.n})"
+
+    class MultiDiscrete(Space):
+        def __init__(self, nvec):
+            self.nvec = np.asarray(nvec, dtype=np.int64)
+            self.shape = self.nvec.shape
+            self.dtype = np.int64
+
+        def sample(self):
+            return (np.random.random(self.shape) * self.nvec).astype(np.int64)
+
+        def __repr__(self):
+            return f"MultiDiscrete({self.nvec.tolist()})"
 
     class Box(Space):
         def __init__(self, low, high, shape=None, dtype=np.float32):
