@@ -18,6 +18,8 @@ static const char *const kDebugKeys[] = {
     "overcooked.whole_max",  // largest single-pass observation tile, bytes
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
+    "overcooked.prio",       // experiment: raise the priority of half of the waves (see overcooked.hip)
+    "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do
     "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition
     "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step

@@ -98,8 +98,14 @@ struct StepParams {
                            // steps it redundantly, takes every kWavesPerBlock-th pass of its rows; wave 0 stores the state
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
+    uint32_t private_consts;  // <= 4 players and <= 4 pots: start cells and pots travel in kernel arguments, the terrain
+                              // in a per-wave LDS copy -> no workgroup barrier in the kernel (the waves never meet)
+    uint32_t starts_w;        // start cells of the first four players, one byte each
+    uint32_t off_terr;        // per-wave terrain copy (private_consts)
+    uint32_t prio_mode;    // experiment knob (mrl_debug_set overcooked.prio): which waves run at raised priority
     uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
-    const uint16_t *terr_pos;  // device, [rows]: offset of a row's terrain one-hot byte inside a world's block, 0xFFFF = none
+    const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
+    uint32_t terr_entries;     // wpw * rows
     uint32_t off_pl, off_x, off_sum, off_cur, off_flags, off_list, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
@@ -688,32 +694,36 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 }
 
 // The static part of the tile: zeros plus one terrain one-hot byte per row of a non-AIR cell
-// (sim.cpp:642-645).  p.terr_pos holds, per row of ONE world, the byte offset of that bit inside the
-// world's block (0xFFFF: none).  A lane takes rows i = lane, lane + 64, ... of the GROUP (world l = i / rows),
-// asks for its table entries together with the state loads and ends up with the tile offsets in registers.
+// (sim.cpp:642-645).  A lane takes rows i = lane, lane + 64, ... of the GROUP and ends up with the tile offsets
+// of their terrain bytes in registers.
 // (Copying a ready-made background image from global memory instead was measured: 10 KB per wave through
 // the vector memory pipe, 64 B/clk per CU, cost ~1 us per step.)
 constexpr int kTerrPosPerLane = 10;  // 64 x 10 rows: room for 16-world groups of the smallest layout
 struct TerrPos {
-    uint32_t off[kTerrPosPerLane];  // byte offset in the tile, 0xFFFFFFFF = nothing to set
+    uint32_t off[kTerrPosPerLane];  // byte offset in the tile, 0 = nothing to set (no terrain byte sits at offset 0)
 };
-__device__ __forceinline__ void terrain_request(const StepParams &p, uint32_t lane, uint32_t nw, TerrPos &r)
+// p.terr_off is that table for a whole GROUP (entry i = row i of the group, worlds in order): one bounds-checked
+// 2-byte load per 64 rows, no division, requested together with the state loads
+__device__ __forceinline__ void terrain_request(const StepParams &p, uint32_t lane, TerrPos &r)
 {
-    const uint32_t total = nw * p.rows;
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.terr_off), 0, (int)(p.terr_entries * 2u), 0x00020000);
 #pragma unroll
     for (int k = 0; k < kTerrPosPerLane; k++) {
-        const uint32_t i = lane + (uint32_t)k * kWave;
-        const uint32_t l = __umulhi(i, p.inv_rows), row = i - __umul24(l, p.rows);
-        // unconditional load (see the state loads); rows beyond the group are masked afterwards
-        const uint32_t pos = p.terr_pos[i < total ? row : 0u];
-        r.off[k] = (i < total && pos != 0xFFFFu) ? __umul24(l, p.block_bytes) + pos : 0xFFFFFFFFu;
+        if ((uint32_t)k * kWave >= p.terr_entries) {  // wave-uniform
+            r.off[k] = 0;
+            continue;
+        }
+        r.off[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(tab, (int)((lane + (uint32_t)k * kWave) * 2u), 0, 0);
     }
 }
-__device__ __forceinline__ void terrain_deliver(uint32_t lane, const TerrPos &r, uint8_t *tile)
+__device__ __forceinline__ void terrain_deliver(const StepParams &p, const TerrPos &r, uint8_t *tile, uint32_t nw)
 {
+    const uint32_t limit = nw * p.block_bytes;  // a ragged last group holds fewer worlds
 #pragma unroll
-    for (int k = 0; k < kTerrPosPerLane; k++)
-        if (r.off[k] != 0xFFFFFFFFu) tile[r.off[k]] = 1;
+    for (int k = 0; k < kTerrPosPerLane; k++) {
+        if ((uint32_t)k * kWave >= p.terr_entries) break;
+        if (r.off[k] != 0u && r.off[k] < limit) tile[r.off[k]] = 1;
+    }
 }
 __device__ __forceinline__ void tile_zero(const StepParams &p, uint32_t lane, uint8_t *tile, uint32_t nw)
 {
@@ -790,12 +800,29 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     STAMP(0);
     STAMP_REALTIME(13);
     if (ABLATED(16)) return;  // diagnostic build: the empty launch
-    // the constant block and the group's state slab are fetched together: one HBM/L2 latency
+    if (p.prio_mode) {
+        const uint32_t sel = p.prio_mode & 3u;
+        const bool fast = sel == 1 ? ((blockIdx.x >> 3) & 1u) != 0 : sel == 2 ? (wib & 1u) != 0 : ((blockIdx.x >> 4) & 1u) != 0;
+        if (fast) {
+            if (p.prio_mode & 4u)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(3);
+        }
+    }
+    // the constants and the group's state slab are fetched together: one HBM/L2 latency.  Small configurations
+    // (p.private_consts) need only the terrain in LDS, one private copy per wave: no barrier, the waves never meet.
     constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
     uint32_t const_word[kConstWordsPerThread];
+    const bool private_consts = p.private_consts != 0;  // wave-uniform
+    if (private_consts) {
+        const __amdgpu_buffer_rsrc_t r_terr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.consts), 0, (int)((p.C + 3u) & ~3u), 0x00020000);
+        const_word[0] = __builtin_amdgcn_raw_buffer_load_b32(r_terr, (int)(lane * 4u), 0, 0);
+    } else {
 #pragma unroll
-    for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
-    const uint8_t *s_terrain = smem + kConstTerrain;
+        for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
+    }
+    const uint8_t *s_terrain = private_consts ? smem + kConstBytes + wib * p.lds_wave_stride + p.off_terr : smem + kConstTerrain;
     const uint8_t *s_start = smem + kConstStart;
     const uint8_t *s_pots = smem + kConstPots;
 
@@ -836,20 +863,19 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     // 2.1 us -- three to four dependent HBM/L2 latencies -- for a 1.2 KB slab).
     if (!kInit) {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
-        const uint2 *g_pl = p.players + (size_t)w0 * P;
         constexpr int kBatch = 4;
         uint32_t cell_reg[kBatch];
+        // bounds-checked buffer loads: lanes beyond the group's slab read zero, no branch around any load (behind a
+        // branch hipcc consumes a load on the spot, `s_waitcnt vmcnt(0)` before the others are even issued)
+        const __amdgpu_buffer_rsrc_t r_obj = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(g_obj), 0, (int)(ncells * 4u), 0x00020000);
 #pragma unroll
-        for (int k = 0; k < kBatch; k++) {
-            const uint32_t i = lane + k * kWave;
-            cell_reg[k] = i < ncells ? g_obj[i] : 0u;
-        }
-        // unconditional, clamped indices: behind a branch hipcc consumes a load on the spot (`s_waitcnt vmcnt(0)`
-        // before the other loads of the group are even issued -- one more HBM latency)
-        const uint2 pl_reg = g_pl[active ? lane : 0u];
+        for (int k = 0; k < kBatch; k++) cell_reg[k] = __builtin_amdgcn_raw_buffer_load_b32(r_obj, (int)((lane + (uint32_t)k * kWave) * 4u), 0, 0);
+        const __amdgpu_buffer_rsrc_t r_pl = __builtin_amdgcn_make_buffer_rsrc(p.players + (size_t)w0 * P, 0, (int)(nplayers * 8u), 0x00020000);
+        const auto pl_raw = __builtin_amdgcn_raw_buffer_load_b64(r_pl, (int)(lane * 8u), 0, 0);
+        const uint2 pl_reg = make_uint2(pl_raw[0], pl_raw[1]);
         const uint32_t a_raw = (uint32_t)p.actions[(size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u)];
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
-        if (p.patch) terrain_request(p, lane, nw, tpos);
+        if (p.patch) terrain_request(p, lane, tpos);
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
@@ -871,19 +897,25 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
             held = kItemNone;
         }
     } else {
-        if (p.patch) terrain_request(p, lane, nw, tpos);
+        if (p.patch) terrain_request(p, lane, tpos);
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
             tile_zero_addtid(s_tile, nw * p.block_bytes);
         else if (p.whole)
             tile_zero(p, lane, s_tile, nw);
     }
-    if (p.patch) terrain_deliver(lane, tpos, s_tile);
+    if (p.patch) terrain_deliver(p, tpos, s_tile, nw);
+    if (private_consts) {
+        if (lane * 4u < p.C) reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(s_terrain))[lane] = const_word[0];
+        STAMP(7);
+        wave_lds_sync();
+    } else {
 #pragma unroll
-    for (int j = 0; j < kConstWordsPerThread; j++)
-        if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
-    STAMP(7);
-    __syncthreads();
+        for (int j = 0; j < kConstWordsPerThread; j++)
+            if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
+        STAMP(7);
+        __syncthreads();
+    }
     if (nw == 0) return;
     if (ABLATED(32)) return;  // diagnostic build: launch + loads + barrier
     STAMP(1);
@@ -904,7 +936,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     if (__ballot(active && reset_now) != 0ull) {
         if (reset_now) {
             t = 0;
-            posori = (uint32_t)s_start[active ? q : 0u] | (A_NORTH << 8);
+            posori = (private_consts ? (p.starts_w >> (8u * (q & 3u))) & 0xFFu : (uint32_t)s_start[active ? q : 0u]) | (A_NORTH << 8);
             held = kItemNone;
         }
         if (active && q == 0) s_sum[wl] = reset_now ? 1u : 0u;
@@ -1133,9 +1165,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
     uint32_t const_word[kConstWordsPerThread];
+    const bool private_consts = p.private_consts != 0;  // see mrl_overcooked_step
+    if (private_consts) {
+        const __amdgpu_buffer_rsrc_t r_terr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.consts), 0, (int)((p.C + 3u) & ~3u), 0x00020000);
+        const_word[0] = __builtin_amdgcn_raw_buffer_load_b32(r_terr, (int)(lane * 4u), 0, 0);
+    } else {
 #pragma unroll
-    for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
-    const uint8_t *s_terrain = smem + kConstTerrain;
+        for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
+    }
+    const uint8_t *s_terrain = private_consts ? smem + kConstBytes + wib * p.lds_wave_stride + p.off_terr : smem + kConstTerrain;
     const uint8_t *s_start = smem + kConstStart;
     const uint8_t *s_pots = smem + kConstPots;
     const uint32_t per_xcd = gridDim.x >> 3;
@@ -1169,9 +1207,9 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         t = p.timestep[world];
         TerrPos tpos;
         if (p.patch) {
-            terrain_request(p, lane, nw, tpos);
+            terrain_request(p, lane, tpos);
             tile_zero_addtid(s_tile, nw * p.block_bytes);
-            terrain_deliver(lane, tpos, s_tile);
+            terrain_deliver(p, tpos, s_tile, nw);
             if (lane < 32) s_prev[lane] = 0;
         }
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
@@ -1181,10 +1219,15 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
             held = pl_reg.y;
         }
     }
+    if (private_consts) {
+        if (lane * 4u < p.C) reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(s_terrain))[lane] = const_word[0];
+        wave_lds_sync();
+    } else {
 #pragma unroll
-    for (int j = 0; j < kConstWordsPerThread; j++)
-        if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
-    __syncthreads();
+        for (int j = 0; j < kConstWordsPerThread; j++)
+            if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
+        __syncthreads();
+    }
     if (nw == 0) return;
     if (active) s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
 
@@ -1212,7 +1255,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
         if (__ballot(active && reset_now) != 0ull) {
             if (reset_now) {
                 t = 0;
-                posori = (uint32_t)s_start[active ? q : 0u] | (A_NORTH << 8);
+                posori = (private_consts ? (p.starts_w >> (8u * (q & 3u))) & 0xFFu : (uint32_t)s_start[active ? q : 0u]) | (A_NORTH << 8);
                 held = kItemNone;
             }
             if (active && q == 0) s_sum[wl] = reset_now ? 1u : 0u;
@@ -1490,6 +1533,9 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         memcpy(a.values_w, consts + kConstValues, 16);
         memcpy(&a.pots_w, consts + kConstPots, 4);
         a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
+        a.prio_mode = (uint32_t)mrl::debug_get("overcooked.prio", 0);
+        a.private_consts = (P <= 4 && num_pots <= 4 && !mrl::debug_get("overcooked.shared_consts", 0)) ? 1u : 0u;
+        memcpy(&a.starts_w, consts + kConstStart, 4);
         a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;
         a.steady = (a.wpp > 0 && ((uint64_t)a.wpp * a.block_bytes) % 16 == 0) ? 1u : 0u;
 #ifdef MRL_DIAG
@@ -1517,12 +1563,13 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.off_sum = a.off_x + ((a.P == 2 && !sim->generic) ? 0u : 128u * 4u);
             a.off_cur = a.off_sum + up16(2u * wpw * 4u);
             a.off_flags = a.off_cur + up16(wpw * a.C);
-            a.off_list = a.off_flags + 64u;
+            a.off_terr = a.off_flags + 64u;
+            a.off_list = a.off_terr + (a.private_consts ? up16(a.C) : 0u);
             a.off_tail = a.off_list + up16(wpw * a.C * 2u);
             const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
             // with a background image the slab must start on a 16-byte boundary in every group
-            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave) ? 1u : 0u;
+            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave && wpw * a.block_bytes < 65536u) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 // with a.patch the tile is zeroed in whole 256-byte pieces (tile_zero_addtid)
@@ -1588,17 +1635,19 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
         {
-            // per row of one world: where its terrain one-hot byte goes (channel 5P + t - 1, sim.cpp:642-645)
-            std::vector<uint16_t> pos(a.rows, 0xFFFFu);
-            for (uint32_t v = 0; v < a.P; v++)
-                for (uint32_t c = 0; c < a.C; c++) {
-                    const uint32_t t = consts[kConstTerrain + c];
-                    if (t != T_AIR && (v * a.C + c) * a.F + 5 * a.P + t - 1 < 0xFFFFu)
-                        pos[v * a.C + c] = (uint16_t)((v * a.C + c) * a.F + 5 * a.P + t - 1);
-                }
-            uint16_t *d_pos = sim->arena.alloc<uint16_t>(a.rows, false);
-            MRL_HIP(hipMemcpy(d_pos, pos.data(), a.rows * sizeof(uint16_t), hipMemcpyHostToDevice));
-            a.terr_pos = d_pos;
+            // per row of a group: where its terrain one-hot byte goes in the tile (channel 5P + t - 1, sim.cpp:642-645)
+            a.terr_entries = a.wpw * a.rows;
+            std::vector<uint16_t> off(a.terr_entries, 0);
+            if (a.patch)
+                for (uint32_t l = 0; l < a.wpw; l++)
+                    for (uint32_t v = 0; v < a.P; v++)
+                        for (uint32_t c = 0; c < a.C; c++) {
+                            const uint32_t t = consts[kConstTerrain + c];
+                            if (t != T_AIR) off[l * a.rows + v * a.C + c] = (uint16_t)(l * a.block_bytes + (v * a.C + c) * a.F + 5 * a.P + t - 1);
+                        }
+            uint16_t *d_off = sim->arena.alloc<uint16_t>(a.terr_entries, false);
+            MRL_HIP(hipMemcpy(d_off, off.data(), a.terr_entries * sizeof(uint16_t), hipMemcpyHostToDevice));
+            a.terr_off = d_off;
         }
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
