@@ -245,15 +245,19 @@ int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 /* ------------------------------------------------------------------ */
 
 /* One environment step for every world: replaces Manager::step.
- * Hanabi and Cartpole number new episodes in ascending world order, which takes a
- * prefix sum over the worlds that finished.  mrl_step does it inside ONE launch:
- * each workgroup takes a ticket (one atomic increment) as its index, publishes its
- * count and waits for the lower tickets -- workgroups that are known to have started,
- * so the wait ends whatever the dispatch order (csrc/episode_scan.hpp).  The wait is
- * bounded all the same; if it ever expired the SCAN_TIMEOUT tensor of the game
- * becomes nonzero, the episode numbers from that step on are unspecified, and every
- * later mrl_step* / mrl_rollout_random on the simulator returns MRL_ERR_DEVICE
- * (the host learns it from a word in mapped host memory: no device call, no sync). */
+ * Hanabi, Cartpole and the balance beam number new episodes in ascending world order, which
+ * takes a prefix sum over the worlds that finished.  By default mrl_step is two launches
+ * (phase 1, phase 2: the kernel boundary is the grid-wide hand-off, nothing waits inside a
+ * kernel).  Two kinds of launch DO wait for other workgroups inside the kernel: the
+ * single-launch step behind mrl_debug_set("fused_step") -- each workgroup takes a ticket (one
+ * atomic increment) as its index and waits only for lower tickets, i.e. workgroups known to
+ * have started (csrc/episode_scan.hpp; measured slower than two launches, the tickets
+ * serialise) -- and the persistent multi-step launches of mrl_rollout_random, which need all
+ * their workgroups resident and are therefore launched cooperatively.  Every such wait is
+ * bounded; if one ever expired the SCAN_TIMEOUT tensor of the game becomes nonzero, the
+ * episode numbers from that step on are unspecified, and every later mrl_step* /
+ * mrl_rollout_random on the simulator returns MRL_ERR_DEVICE (the host learns it from a
+ * word in mapped host memory: no device call, no sync). */
 int mrl_step(mrl_sim *sim, void *hip_stream);
 
 /* Launch shape of the simulator's step kernel: out = {workgroups, threads per workgroup, LDS bytes per
@@ -335,7 +339,7 @@ void mrl_destroy(mrl_sim *sim);
 
 /* Test and measurement knobs, consulted by the NEXT mrl_*_create (the library reads no environment
  * variable).  Keys: overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.no_share,
- * overcooked.variant, hanabi.variant, hanabi.no_persistent, cartpole.no_persistent, two_launch_step,
+ * overcooked.variant, hanabi.variant, hanabi.no_persistent, cartpole.no_persistent, fused_step,
  * inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
  * No reference counterpart (the reference has MADRONA_* environment variables for its JIT cache only). */
 int mrl_debug_set(const char *key, int64_t value);

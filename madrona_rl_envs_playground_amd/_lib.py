@@ -126,7 +126,7 @@ def debug_set(key, value):
 
 
 class debug_knobs:
-    """``with debug_knobs({"two_launch_step": 1}): sim = ...`` -- knobs apply to simulators created inside."""
+    """``with debug_knobs({"fused_step": 1}): sim = ...`` -- knobs apply to simulators created inside."""
 
     def __init__(self, knobs):
         self.knobs = dict(knobs)

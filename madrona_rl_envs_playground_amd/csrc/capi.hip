@@ -18,13 +18,15 @@ static const char *const kDebugKeys[] = {
     "overcooked.whole_max",  // largest single-pass observation tile, bytes
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
+    "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
     "overcooked.prio",       // experiment: raise the priority of half of the waves (see overcooked.hip)
     "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do
     "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition
     "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
-    "two_launch_step",       // 1: mrl_step as phase 1 + phase 2 launches (Hanabi, Cartpole)
+    "fused_step",            // 1: mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel ticketed prefix (episode_scan.hpp)
+                             // instead of the default phase 1 + phase 2 launches (measured slower)
     "inject_scan_timeout",   // 1: the simulator's SCAN_TIMEOUT alarm is raised right after construction (tests of the error path)
     "ablate",                // diagnostic build only: phase ablation mask
     "stamps",                // diagnostic build only: in-kernel time stamps

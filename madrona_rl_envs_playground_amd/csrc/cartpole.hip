@@ -422,9 +422,11 @@ struct CartpoleSim final : mrl_sim {
     uint32_t fused_grid = 0, epoch = 0;
     bool scan_timed_out() const override { return alarm.raised(); }
 
+    bool fused_step = false;  // mrl_debug_set fused_step: one launch with the ticketed in-kernel prefix instead of two launches
+
     void step(const int32_t *actions, hipStream_t stream) override
     {
-        if (fused_grid == 0) {
+        if (fused_grid == 0 || !fused_step) {
             mrl_sim::step(actions, stream);
             return;
         }
@@ -469,7 +471,7 @@ struct CartpoleSim final : mrl_sim {
             persistent_ok = false;
         }
         for (uint32_t k = 0; k < num_steps; k++) {
-            if (fused_grid) {
+            if (fused_grid && fused_step) {
                 launch_fused(action, action, seed, first_step + k, stream);
             } else {
                 hipLaunchKernelGGL(mrl_cartpole_draw_actions, dim3((num_worlds + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
@@ -527,7 +529,7 @@ struct CartpoleSim final : mrl_sim {
     }
 
     size_t action_elems() const override { return (size_t)num_worlds; }
-    const char *kernel_name() const override { return fused_grid ? "mrl_cartpole_step_fused" : "mrl_cartpole_step"; }
+    const char *kernel_name() const override { return fused_grid && fused_step ? "mrl_cartpole_step_fused" : "mrl_cartpole_step"; }
     uint64_t bytes_per_world_step() const override { return 44; }
 };
 
@@ -561,12 +563,13 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         {
             const uint32_t blocks = (num_worlds + kUnroll * kBlock - 1) / (kUnroll * kBlock);
-            if (blocks <= mrl::kMaxFusedBlocks && !mrl::debug_get("two_launch_step", 0)) {
+            if (blocks <= mrl::kMaxFusedBlocks) {
                 sim->fused_grid = blocks;
                 sim->status = sim->arena.alloc<unsigned long long>(blocks);
             }
         }
         sim->alarm.init(sim->arena);
+        sim->fused_step = mrl::debug_get("fused_step", 0) != 0;
         sim->ticket = sim->arena.alloc<uint32_t>(1);
         if (sim->fused_grid) {
             int per_cu = 0, cus = 0;

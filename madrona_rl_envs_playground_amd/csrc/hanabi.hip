@@ -41,7 +41,7 @@ namespace {
 
 constexpr int kWave = 64;
 #ifndef MRL_HANABI_WPB
-#define MRL_HANABI_WPB 4
+#define MRL_HANABI_WPB 8
 #endif
 #ifndef MRL_HANABI_WPW
 #define MRL_HANABI_WPW 32
@@ -1685,7 +1685,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->alarm.init(sim->arena);
         sim->ticket = sim->arena.alloc<uint32_t>(1);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
-        sim->fused = !mrl::debug_get("two_launch_step", 0);
+        sim->fused = mrl::debug_get("fused_step", 0) != 0;  // default: two launches, the kernel boundary is the grid-wide hand-off
         {
             // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each
             // other: only usable when the grid fits the GPU in one go and each workgroup owns one sub-block
@@ -1698,7 +1698,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
             // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
             // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)
             const int usable = per_cu > 4 ? per_cu - 1 : per_cu;
-            sim->persistent_ok = sim->fused && !mrl::debug_get("hanabi.no_persistent", 0) && sim->params.chunk == (uint32_t)kWorldsPerBlock &&
+            sim->persistent_ok = !mrl::debug_get("hanabi.no_persistent", 0) && sim->params.chunk == (uint32_t)kWorldsPerBlock &&
                                  (uint64_t)sim->grid <= (uint64_t)usable * (uint64_t)cus;
             sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->grid);
         }

@@ -1599,7 +1599,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         while (wpw > 1 && (layout(wpw) > lds_max || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
             wpw >>= 1;
-        sim->lds_bytes = layout(wpw);
+        sim->lds_bytes = layout(wpw) + (uint32_t)mrl::debug_get("overcooked.lds_pad", 0);  // the pad: residency experiments
         if (sim->lds_bytes > 65536) {
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));

@@ -77,9 +77,14 @@ def test_lockstep_vs_oracle(n, steps, hip_lib, oracle_lib):
 
 @pytest.mark.parametrize("n,steps", [(5000, 120), (300001, 60), (1 << 20, 25)])
 def test_two_phase_equals_single_call(n, steps, hip_lib):
-    """mrl_step is one fused launch (workgroups wait for each other's counts inside the kernel);
-    the two-phase calls are two launches with the prefix between them.  Same numbers either way."""
-    s1, s2 = make(n), make(n)
+    """mrl_debug_set("fused_step"): mrl_step as ONE launch (workgroups take a ticket and wait for the lower
+    tickets' counts inside the kernel); the two-phase calls are two launches with the prefix between them.
+    Same numbers either way."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    with debug_knobs({"fused_step": 1}):
+        s1 = make(n)
+    s2 = make(n)
+    assert s1.kernel_name == "mrl_cartpole_step_fused" and s2.kernel_name == "mrl_cartpole_step"
     torch.manual_seed(1)
     for _ in range(steps):
         a = torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda")

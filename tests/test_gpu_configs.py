@@ -214,3 +214,25 @@ def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, ora
     loop.rollout(env, ego, buffers, ob, steps, on_step=check)
     assert seen["steps"] == steps and seen["dones"] == 2 * n  # two horizons crossed
     env.close()
+
+
+def test_several_layouts_as_one_batch(hip_lib):
+    """OvercookedMultiLayout: the five standard layouts stepped side by side on their own streams give, layout by
+    layout, what five separate envs give."""
+    from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
+    from madrona_rl_envs_playground_amd.envs.multi_layout import OvercookedMultiLayout
+    counts = [300, 77, 512, 64, 129]
+    multi = OvercookedMultiLayout(STANDARD, counts, 0, horizon=35)
+    singles = [OvercookedMadrona(name, n, 0, horizon=35) for name, n in zip(STANDARD, counts)]
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    for _ in range(80):
+        acts = [torch.randint(0, 6, (2, n, 1), device="cuda", generator=gen) for n in counts]
+        got = multi.n_step(acts)
+        for k, env in enumerate(singles):
+            obs, rew, done, _ = env.n_step(acts[k])
+            mobs, mrew, mdone, _ = got[k]
+            assert all(torch.equal(a.obs, b.obs) for a, b in zip(obs, mobs)), STANDARD[k]
+            assert torch.equal(rew, mrew) and torch.equal(done, mdone)
+    multi.close()
+    for env in singles:
+        env.close()

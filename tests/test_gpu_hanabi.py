@@ -141,9 +141,12 @@ def test_full_game_encoder_matches_generic_encoder(hip_lib):
 
 @pytest.mark.parametrize("cfg,n,steps", [(FULL, 5000, 80), (FULL, 70001, 40), (SMALL, 3000, 60)], ids=["full", "full_70001", "small"])
 def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
-    """mrl_step is one fused launch (workgroups exchange their finished counts inside the
-    kernel); the two-phase calls are two launches.  Same tensors either way."""
-    s1, s2 = make(cfg, n), make(cfg, n)
+    """mrl_debug_set("fused_step"): mrl_step as ONE launch (workgroups take a ticket and exchange their finished
+    counts inside the kernel); the two-phase calls are two launches.  Same tensors either way."""
+    with debug_knobs({"fused_step": 1}):
+        s1 = make(cfg, n)
+    s2 = make(cfg, n)
+    assert s1.kernel_name == "mrl_hanabi_step_fused" and s2.kernel_name == "mrl_hanabi_step"
     gen = torch.Generator(device="cuda").manual_seed(11)
     mask = s1.action_mask_tensor().to_torch()
     names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor",
@@ -164,13 +167,13 @@ def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
     s2.close()
 
 
-@pytest.mark.parametrize("two_launch", [False, True], ids=["single_launch", "two_launch"])
-def test_device_random_policy(two_launch, hip_lib, oracle_lib):
+@pytest.mark.parametrize("fused", [True, False], ids=["single_launch", "two_launch"])
+def test_device_random_policy(fused, hip_lib, oracle_lib):
     """mrl_rollout_random == the oracle fed the documented stream (uniform over the mover's legal
     moves, include/mrl_envs.h): checked step by step, then a multi-step call against a replay."""
     from madrona_rl_envs_playground_amd.simulators import random_hanabi_action
     n, seed = 2500, 0xC0FFEE1234
-    with debug_knobs({"two_launch_step": 1} if two_launch else {}):
+    with debug_knobs({"fused_step": 1} if fused else {}):
         sim, twin = make(FULL, n), make(FULL, n)
     orc = oracle_lib.HanabiOracle(FULL, n, num_threads=8)
     world = np.arange(n)

@@ -10,7 +10,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, ExecMode, HanabiSimulator  # noqa: E402
+from madrona_rl_envs_playground_amd import layouts  # noqa: E402
+from madrona_rl_envs_playground_amd.simulators import (BalanceBeamSimulator, CartpoleSimulator, ExecMode, HanabiSimulator,  # noqa: E402
+                                                       SimplecookedSimulator)
 
 
 def timed(fn, steps, warmup=20):
@@ -32,7 +34,12 @@ def main():
     ap.add_argument("--hanabi-worlds", type=int, default=65536)
     ap.add_argument("--cartpole-worlds", type=int, default=1048576)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--knob", action="append", default=[], help="key=value for mrl_debug_set (measurement variants)")
     args = ap.parse_args()
+    from madrona_rl_envs_playground_amd import _lib
+    for kv in args.knob:
+        k, v = kv.split("=")
+        _lib.debug_set(k, int(v))
 
     n = args.hanabi_worlds
     sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
@@ -78,6 +85,24 @@ def main():
     dev = e0.elapsed_time(e1) / args.steps * 1e-3
     out["cartpole"].update({"us_per_step_device_policy": dev * 1e6, "steps_per_s_device_policy": n / dev})
     sim.close()
+    # the sibling worlds: Simplecooked `simple` at the headline's batch size, balance beam
+    n = 32768
+    params = layouts.get_simplecooked_layout_params("simple", 200)
+    sim = SimplecookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+    pool = [torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(8)]
+    wall, dev = timed(lambda i: sim.step_with_actions(pool[i % 8]), 1000)
+    gbps = sim.bytes_per_world_step * n / dev / 1e9
+    out["simplecooked"] = {"layout": "simple", "worlds": n, "us_per_step": dev * 1e6, "steps_per_s": n / dev, "bytes_per_world_step":
+                           sim.bytes_per_world_step, "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0, "kernel": sim.kernel_name}
+    sim.close()
+    n = 1 << 20
+    sim = BalanceBeamSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
+    pool = [torch.randint(0, 4, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(8)]
+    wall, dev = timed(lambda i: sim.step_with_actions(pool[i % 8]), args.steps)
+    out["balance_beam"] = {"worlds": n, "us_per_step": dev * 1e6, "steps_per_s": n / dev,
+                           "algorithmic_GBps": sim.bytes_per_world_step * n / dev / 1e9}
+    sim.close()
+    out["knobs"] = args.knob
     print(json.dumps(out))
 
 
