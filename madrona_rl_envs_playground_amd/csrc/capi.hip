@@ -113,30 +113,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int kMode>
 __global__ void __launch_bounds__(256) mrl_probe_stream_kernel(f32x4 *__restrict__ dst, const f32x4 *__restrict__ src, size_t chunks)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // every workgroup streams through ONE contiguous range (like a wave of the step kernels writing its group's
+    // slab): 4 x 4 KB in flight per workgroup and trip
+    const size_t per_block = (chunks + gridDim.x - 1) / gridDim.x;
+    const size_t first = (size_t)blockIdx.x * per_block, last = first + per_block < chunks ? first + per_block : chunks;
     const f32x4 fill = {1.f, 2.f, 3.f, 4.f};
-    for (; i + 3 * stride < chunks; i += 4 * stride) {
+    size_t i = first + threadIdx.x;
+    for (; i + 3 * 256 < last; i += 4 * 256) {
         f32x4 a = fill, b = fill, c = fill, d = fill;
         if (kMode == 0) {
             a = src[i];
-            b = src[i + stride];
-            c = src[i + 2 * stride];
-            d = src[i + 3 * stride];
+            b = src[i + 256];
+            c = src[i + 512];
+            d = src[i + 768];
         }
         if (kMode == 2) {  // write-through, like the observation stores of the step kernels
             asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i), "v"(a) : "memory");
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + stride), "v"(b) : "memory");
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 2 * stride), "v"(c) : "memory");
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 3 * stride), "v"(d) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 256), "v"(b) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + i + 512), "v"(c) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst + i + 768), "v"(d) : "memory");
         } else {
             dst[i] = a;
-            dst[i + stride] = b;
-            dst[i + 2 * stride] = c;
-            dst[i + 3 * stride] = d;
+            dst[i + 256] = b;
+            dst[i + 512] = c;
+            dst[i + 768] = d;
         }
     }
-    for (; i < chunks; i += stride) dst[i] = kMode == 0 ? src[i] : fill;
+    for (; i < last; i += 256) dst[i] = kMode == 0 ? src[i] : fill;
 }
 
 }  // namespace mrl
@@ -313,7 +316,7 @@ int mrl_probe_stream(void *dst_dev, const void *src_dev, uint64_t bytes, int mod
     mrl::DeviceGuard on(gpu_id);
     return guarded([&] {
         const size_t chunks = bytes / 16;
-        const unsigned grid = (unsigned)std::min<size_t>((chunks + 1023) / 1024, 256 * 16);
+        const unsigned grid = (unsigned)std::min<size_t>((chunks + 1023) / 1024, 256 * 32);
         auto *dst = static_cast<mrl::f32x4 *>(dst_dev);
         auto *src = static_cast<const mrl::f32x4 *>(src_dev);
         hipStream_t stream = (hipStream_t)hip_stream;
