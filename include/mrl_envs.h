@@ -273,6 +273,13 @@ int mrl_scan_timed_out(const mrl_sim *sim);
  * reference wrappers make (static_actions.copy_, envs/overcooked_env.py:107). */
 int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream);
 
+/* The same with the caller's actions as int64 (same shape and layout): what the reference's harness hands
+ * `env.n_step` (scripts/overcooked_example.py:99-106: `torch.randint_like` of a long tensor), which the reference
+ * wrapper narrows with a gather + copy kernel per step (envs/overcooked_env.py:104-107).  Here the step kernel reads
+ * the 8-byte values itself and mirrors them into the ACTION tensor, so the wrapped step is one launch.  Overcooked and
+ * Simplecooked; MRL_ERR_INVALID for the other games. */
+int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hip_stream);
+
 /* Two-phase step for world batches sharded over several GPUs (Hanabi and
  * Cartpole draw each new episode's seed from one global counter,
  * src/hanabi_env/sim.cpp:449-451, src/cartpole_env/sim.cpp:51-53):

@@ -29,7 +29,7 @@ SYMBOLS = [
     "mrl_step_phase1", "mrl_step_phase2", "mrl_set_episode_counter", "mrl_reseed_shard", "mrl_tensor", "mrl_game",
     "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
-    "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create",
+    "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
 ]
 ABI_VERSION = 2  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
@@ -92,6 +92,7 @@ def lib():
     L.mrl_balance_create.argtypes = [i32, u32, ctypes.POINTER(vp)]
     L.mrl_step.argtypes = [vp, vp]
     L.mrl_step_with_actions.argtypes = [vp, vp, vp]
+    L.mrl_step_with_actions_i64.argtypes = [vp, vp, vp]
     L.mrl_step_phase1.argtypes = [vp, vp, vp]
     L.mrl_step_phase2.argtypes = [vp, vp, vp]
     L.mrl_set_episode_counter.argtypes = [vp, u32, vp]

@@ -205,6 +205,24 @@ int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_st
     return guarded([&] { sim->step(actions_dev, (hipStream_t)hip_stream); });
 }
 
+int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hip_stream)
+{
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    if (!actions_dev) {
+        mrl::set_error("mrl_step_with_actions_i64: null action array");
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(sim->device);
+    int rc = MRL_OK;
+    const int g = guarded([&] {
+        if (!sim->step_i64(reinterpret_cast<const long long *>(actions_dev), (hipStream_t)hip_stream)) {
+            mrl::set_error("mrl_step_with_actions_i64: not available for game %d; convert to int32 and use mrl_step_with_actions", sim->game);
+            rc = MRL_ERR_INVALID;
+        }
+    });
+    return g != MRL_OK ? g : rc;
+}
+
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;

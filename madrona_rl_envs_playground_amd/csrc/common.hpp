@@ -156,6 +156,9 @@ struct mrl_sim {
         phase1(actions, stream);
         phase2(nullptr, stream);
     }
+    // whole step reading the caller's int64 action tensor (what the reference's harness hands its wrapper); false:
+    // this game has no such path and the caller should convert
+    virtual bool step_i64(const long long *, hipStream_t) { return false; }
     // num_steps steps driven by a caller-provided action array of num_steps consecutive ACTION tensors;
     // default: one launch per step (`action_elems` = elements of one ACTION tensor)
     virtual size_t action_elems() const = 0;

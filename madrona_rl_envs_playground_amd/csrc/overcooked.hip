@@ -114,6 +114,8 @@ struct StepParams {
     uint2 *players;
     int32_t *timestep;
     const int32_t *actions;
+    const long long *actions64;  // mrl_step_with_actions_i64: the caller's int64 action tensor, read directly (NULL otherwise)
+    int32_t *action_mirror;      // ... and mirrored into the ACTION tensor, which the reference's wrapper fills itself
     int32_t *reward;
     int32_t *done;
     uint8_t *obs;
@@ -873,7 +875,8 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         const __amdgpu_buffer_rsrc_t r_pl = __builtin_amdgcn_make_buffer_rsrc(p.players + (size_t)w0 * P, 0, (int)(nplayers * 8u), 0x00020000);
         const auto pl_raw = __builtin_amdgcn_raw_buffer_load_b64(r_pl, (int)(lane * 8u), 0, 0);
         const uint2 pl_reg = make_uint2(pl_raw[0], pl_raw[1]);
-        const uint32_t a_raw = (uint32_t)p.actions[(size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u)];
+        const size_t a_at = (size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u);
+        const uint32_t a_raw = p.actions64 ? (uint32_t)p.actions64[a_at] : (uint32_t)p.actions[a_at];
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
         if (p.patch) terrain_request(p, lane, tpos);
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
@@ -892,6 +895,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
         posori = pl_reg.x & 0xFFFFu;
         held = pl_reg.y;
         act = (active && a_raw <= A_INTERACT) ? a_raw : (uint32_t)A_STAY;  // outside the enum = outside the contract
+        if (p.actions64 && active && (!p.share || wib == 0)) p.action_mirror[a_at] = (int32_t)a_raw;
         if (!active) {
             posori = 0;
             held = kItemNone;
@@ -1340,6 +1344,15 @@ struct OvercookedSim final : mrl_sim {
     }
 
     void phase1(const int32_t *actions, hipStream_t stream) override { launch(false, actions, stream); }
+    bool step_i64(const long long *actions, hipStream_t stream) override
+    {
+        const long long *keep = params.actions64;
+        params.actions64 = actions;
+        params.action_mirror = action;
+        launch(false, nullptr, stream);
+        params.actions64 = keep;
+        return true;
+    }
     void phase2(const uint32_t *, hipStream_t) override {}
 
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override

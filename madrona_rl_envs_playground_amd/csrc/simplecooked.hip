@@ -72,6 +72,7 @@ struct SimpleParams {
     uint2 *players;
     int2 *clock;  // {timestep, num_dishes_out}
     const int32_t *actions;
+    const long long *actions64;  // mrl_step_with_actions_i64 (NULL otherwise); mirrored into the ACTION tensor through action_out
     int32_t *reward;
     int32_t *done;
     uint8_t *obs;
@@ -309,6 +310,8 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
         uint32_t a_raw;
         if (p.sample)  // uniform over the six actions (include/mrl_envs.h: mrl_rollout_random)
             a_raw = mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, q), 6u);
+        else if (p.actions64)
+            a_raw = (uint32_t)p.actions64[(size_t)q * N + world];
         else
             a_raw = (uint32_t)p.actions[(size_t)q * N + world];
         clock = p.clock[world];
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
         posori = active ? pl_reg.x & 0xFFFFu : 0u;
         held = active ? pl_reg.y : kItemNone;
         act = (active && a_raw <= A_INTERACT) ? a_raw : (uint32_t)A_STAY;  // outside the enum = outside the contract
-        if (p.sample && active) p.action_out[(size_t)q * N + world] = (int32_t)act;
+        if ((p.sample || p.actions64) && active) p.action_out[(size_t)q * N + world] = (int32_t)(p.sample ? act : a_raw);
     } else {
 #pragma unroll
         for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
@@ -492,6 +495,15 @@ struct SimplecookedSim final : mrl_sim {
         launch(false, a, stream);
     }
     void phase2(const uint32_t *, hipStream_t) override {}
+    bool step_i64(const long long *actions, hipStream_t stream) override
+    {
+        SimpleParams a = params;
+        a.actions = action;
+        a.actions64 = actions;
+        a.action_out = action;
+        launch(false, a, stream);
+        return true;
+    }
 
     // uniform random policy on the device: the draw happens in the step kernel, one launch per step
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override

@@ -74,8 +74,14 @@ class OvercookedMadrona(VectorMultiAgentEnv):
 
     def n_step(self, actions):
         # (P, N, 1) int64/int32 on any device -> the simulator's int32 action tensor
-        self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
-        self.sim.step()
+        if (actions.dtype == torch.int64 and actions.is_cuda and actions.device == self.static_actions.device and
+                actions.is_contiguous() and actions.numel() == self.static_actions.numel()):
+            # what the reference's harness passes (randint_like of a long tensor): the step kernel reads it as it is and
+            # mirrors it into static_actions, which the reference fills with a copy kernel of its own (overcooked_env.py:107)
+            self.sim.step_with_actions_i64(actions)
+        else:
+            self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
+            self.sim.step()
         return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
 
     def n_reset(self):

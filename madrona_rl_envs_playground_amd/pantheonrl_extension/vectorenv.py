@@ -32,9 +32,67 @@ class DummyEnv:
     action_space: Any
 
 
+class PartnerRoster:
+    """Who plays the non-ego seats.  Seat ``k`` (0-based among the non-ego players) has a list of candidate agents
+    and a cursor into it; the env asks the roster for the seat's current agent, and a resampling policy moves the
+    cursors between episodes.  This is the bookkeeping the reference keeps inline in ``VectorMultiAgentEnv``
+    (vectorenv.py:39-135), pulled out so that the env class is only the step protocol."""
+
+    POLICIES = ("robin", "random")
+
+    def __init__(self, n_players: int, ego_ind: int, candidates: Optional[List[List[VectorAgent]]] = None):
+        self.n_players, self.ego_ind = n_players, ego_ind
+        seats = n_players - 1
+        if candidates is not None:
+            if len(candidates) != seats:
+                raise PlayerException("The number of partners needs to equal the number of non-ego players")
+            if any(not isinstance(c, list) or not c for c in candidates):
+                raise PlayerException("Sublist for each partner must be nonempty list")
+        # like the reference's `[[]] * (n - 1)`, the default seats share ONE list object (a partner added for
+        # player 1 of a 3-player game is also a candidate for player 2)
+        self.candidates = candidates or [[]] * seats
+        self.cursor = [0] * seats
+
+    def seat_of(self, player_num: int) -> int:
+        if player_num == self.ego_ind:
+            raise PlayerException("Ego agent is not set by the environment")
+        return player_num - (1 if player_num > self.ego_ind else 0)
+
+    def player_of(self, seat: int) -> int:
+        return seat + (1 if seat >= self.ego_ind else 0)
+
+    def current(self, seat: int) -> VectorAgent:
+        return self.candidates[seat][self.cursor[seat]]
+
+    def add(self, agent: VectorAgent, player_num: int) -> None:
+        self.candidates[self.seat_of(player_num)].append(agent)
+
+    def choose(self, agent_id: int, player_num: int) -> None:
+        seat = self.seat_of(player_num)
+        assert 0 <= agent_id < len(self.candidates[seat])
+        self.cursor[seat] = agent_id
+
+    def advance(self, policy: str) -> None:
+        if policy == "random":
+            self.cursor = [int(np.random.randint(len(c))) for c in self.candidates]
+        else:  # round robin, two-player games only: one seat
+            self.cursor = [(self.cursor[0] + 1) % len(self.candidates[0])]
+
+    def resolve_policy(self, name: str) -> str:
+        if name == "default":
+            name = "robin" if self.n_players == 2 else "random"
+        if name not in self.POLICIES:
+            raise PlayerException(f"Invalid resampling policy: {name}")
+        if name == "robin" and self.n_players != 2:
+            raise PlayerException("Cannot do round robin resampling for >2 players")
+        return name
+
+
 class VectorMultiAgentEnv(ABC):
-    """N parallel worlds of an ``n_players`` game seen from one "ego" player;
-    the other players are driven by registered partner agents."""
+    """N parallel worlds of an ``n_players`` game seen from one "ego" player; the other players are driven by
+    registered partner agents.  Public names and behaviour are the reference's (vectorenv.py:26-255): ``step`` /
+    ``reset`` for the ego, ``n_step`` / ``n_reset`` for all players, ``add_partner_agent``, ``set_partnerid``,
+    ``resample_*``, ``partners`` / ``partnerids``."""
 
     def __init__(self, num_envs: int, device: torch.device, ego_ind: int = 0, n_players: int = 2,
                  resample_policy: str = "default", partners: Optional[List[List[VectorAgent]]] = None):
@@ -42,76 +100,73 @@ class VectorMultiAgentEnv(ABC):
         self.device = device
         self.ego_ind = ego_ind
         self.n_players = n_players
-        if partners is not None:
-            if len(partners) != n_players - 1:
-                raise PlayerException("The number of partners needs to equal the number of non-ego players")
-            for plist in partners:
-                if not isinstance(plist, list) or not plist:
-                    raise PlayerException("Sublist for each partner must be nonempty list")
-        # NB: like the reference (`[[]] * (n - 1)`) the default lists are one shared object
-        self.partners = partners or [[]] * (n_players - 1)
-        self.partnerids = [0] * (n_players - 1)
+        self._roster = PartnerRoster(n_players, ego_ind, partners)
         self._obs = tuple()
         self._actions = None
         self.set_resample_policy(resample_policy)
+
+    # the reference exposes these two as plain attributes; callers read and occasionally assign them
+    @property
+    def partners(self):
+        return self._roster.candidates
+
+    @partners.setter
+    def partners(self, value):
+        self._roster.candidates = value
+
+    @property
+    def partnerids(self):
+        return self._roster.cursor
+
+    @partnerids.setter
+    def partnerids(self, value):
+        self._roster.cursor = list(value)
 
     def getDummyEnv(self, player_num: int):  # noqa: N802  (reference name)
         return self
 
     def _get_partner_num(self, player_num: int) -> int:
-        if player_num == self.ego_ind:
-            raise PlayerException("Ego agent is not set by the environment")
-        return player_num - 1 if player_num > self.ego_ind else player_num
+        self._roster.ego_ind = self.ego_ind  # subclasses set ego_ind after construction
+        return self._roster.seat_of(player_num)
 
     def add_partner_agent(self, agent: VectorAgent, player_num: int = 1) -> None:
-        self.partners[self._get_partner_num(player_num)].append(agent)
+        self._roster.ego_ind = self.ego_ind
+        self._roster.add(agent, player_num)
 
     def set_partnerid(self, agent_id: int, player_num: int = 1) -> None:
-        partner_num = self._get_partner_num(player_num)
-        assert 0 <= agent_id < len(self.partners[partner_num])
-        self.partnerids[partner_num] = agent_id
+        self._roster.ego_ind = self.ego_ind
+        self._roster.choose(agent_id, player_num)
 
     def resample_random(self) -> None:
-        self.partnerids = [np.random.randint(len(plist)) for plist in self.partners]
+        self._roster.advance("random")
 
     def resample_round_robin(self) -> None:
-        self.partnerids = [(self.partnerids[0] + 1) % len(self.partners[0])]
+        self._roster.advance("robin")
 
     def set_resample_policy(self, resample_policy: str) -> None:
-        if resample_policy == "default":
-            resample_policy = "robin" if self.n_players == 2 else "random"
-        if resample_policy == "robin" and self.n_players != 2:
-            raise PlayerException("Cannot do round robin resampling for >2 players")
-        if resample_policy == "robin":
-            self.resample_partner = self.resample_round_robin
-        elif resample_policy == "random":
-            self.resample_partner = self.resample_random
-        else:
-            raise PlayerException(f"Invalid resampling policy: {resample_policy}")
+        policy = self._roster.resolve_policy(resample_policy)
+        self.resample_partner = self.resample_round_robin if policy == "robin" else self.resample_random
 
     def _get_actions(self, obs, ego_act=None):
-        actions = []
-        for player, ob in zip(range(self.n_players), obs):
-            if player == self.ego_ind:
-                actions.append(ego_act)
-            else:
-                p = self._get_partner_num(player)
-                actions.append(self.partners[p][self.partnerids[p]].get_action(ob))
+        """Joint action (n_players, num_envs, 1): the ego's plus what each seat's current agent answers."""
+        self._roster.ego_ind = self.ego_ind
+        joint = [ego_act if player == self.ego_ind else self._roster.current(self._roster.seat_of(player)).get_action(ob)
+                 for player, ob in zip(range(self.n_players), obs)]
         if self._actions is None:
-            self._actions = torch.stack(actions)
+            self._actions = torch.stack(joint)
         else:
-            torch.stack(actions, out=self._actions)
+            torch.stack(joint, out=self._actions)
         return self._actions
 
     def _update_players(self, rews, done):
-        for i in range(self.n_players - 1):
-            playernum = i + (0 if i < self.ego_ind else 1)
-            self.partners[i][self.partnerids[i]].update(rews[playernum], done)
+        self._roster.ego_ind = self.ego_ind
+        for seat in range(self.n_players - 1):
+            self._roster.current(seat).update(rews[self._roster.player_of(seat)], done)
 
     def step(self, action: torch.Tensor):
         """One timestep from the ego player's point of view -> (obs, reward, done, info)."""
-        acts = self._get_actions(self._obs, action)
-        self._obs, rews, done, info = self.n_step(acts)
+        joint = self._get_actions(self._obs, action)
+        self._obs, rews, done, info = self.n_step(joint)
         self._update_players(rews, done)
         return self._obs[self.ego_ind], rews[self.ego_ind], done, info
 

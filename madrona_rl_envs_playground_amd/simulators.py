@@ -172,6 +172,17 @@ class _Simulator:
         if rc:
             _lib.check(rc)
 
+    def step_with_actions_i64(self, actions):
+        """Step reading ``actions`` as int64 (the ACTION tensor's shape, contiguous, on this GPU): the step kernel narrows
+        them itself and mirrors them into the ACTION tensor (``mrl_step_with_actions_i64``; Overcooked, Simplecooked)."""
+        if (not isinstance(actions, torch.Tensor) or not actions.is_cuda or actions.device.index != self.gpu_id or
+                actions.dtype != torch.int64 or not actions.is_contiguous() or actions.numel() != self._action_numel):
+            raise ValueError("actions must be a contiguous int64 tensor of the ACTION tensor's size on the simulator's device")
+        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        rc = self._L.mrl_step_with_actions_i64(self._handle, actions.data_ptr(), stream)
+        if rc:
+            _lib.check(rc)
+
     def step_sequence(self, actions):
         """One step per leading index of ``actions`` (int32, shape (K,) + ACTION tensor's shape, contiguous,
         on this GPU): same results as K ``step_with_actions`` calls (``mrl_step_sequence``)."""

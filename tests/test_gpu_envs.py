@@ -46,6 +46,35 @@ def test_overcooked_env_matches_reference_numpy_fixture(hip_lib):
     env.close()
 
 
+@pytest.mark.parametrize("which", ["overcooked", "simplecooked"])
+def test_wrapped_step_reads_int64_device_actions_directly(which, hip_lib, oracle_lib):
+    """The reference's harness hands `env.n_step` an int64 tensor on the device (scripts/overcooked_example.py:99-106).
+    The wrappers pass it straight to the step kernel (mrl_step_with_actions_i64): same results as the oracle, and
+    `static_actions` mirrors the actions like the reference's copy would."""
+    n, horizon = 3000, 45
+    if which == "overcooked":
+        env = OvercookedMadrona("coordination_ring", n, 0, horizon=horizon)
+        orc = oracle_lib.OvercookedOracle(env.base_layout_params, n, num_threads=4)
+    else:
+        from madrona_rl_envs_playground_amd.envs.overcooked2_env import OvercookedMadrona as Simplecooked
+        env = Simplecooked("random1", n, 0, horizon=horizon)
+        orc = oracle_lib.SimplecookedOracle(env.base_layout_params, n, num_threads=4)
+    P, H, W = 2, env.height, env.width
+    F = orc.F
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(100):
+        a = torch.randint(0, 6, (P, n, 1), device="cuda", generator=gen)   # int64, like randint_like of a long tensor
+        assert a.dtype == torch.int64
+        obs, rew, done, _ = env.n_step(a)
+        orc.step(a[..., 0].cpu().numpy())
+        want = orc.obs.reshape(n, P, H, W, F).transpose(0, 1, 3, 2, 4)
+        for p in range(P):
+            assert np.array_equal(obs[p].obs.cpu().numpy().astype(np.uint8), want[:, p]), f"step {t}"
+        assert np.array_equal(rew.cpu().numpy(), orc.reward) and np.array_equal(done.cpu().numpy(), orc.done)
+        assert torch.equal(env.static_actions, a.to(torch.int32))
+    env.close()
+
+
 def test_overcooked_ego_step_with_random_partner(hip_lib):
     n = 64
     env = OvercookedMadrona("coordination_ring", n, 0, horizon=30)
