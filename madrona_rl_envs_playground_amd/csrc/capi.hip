@@ -19,6 +19,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
+    "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size
     "overcooked.prio",       // experiment: raise the priority of half of the waves (see overcooked.hip)
     "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do
     "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition

@@ -791,7 +791,7 @@ __device__ __forceinline__ void tile_zero_addtid(uint8_t *tile, uint32_t nbytes)
 #endif
 
 template <bool kInit, int kP>
-__global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
+__device__ __forceinline__ void step_body(const StepParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -1141,6 +1141,85 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p
     STAMP_REALTIME(14);
 }
 
+template <bool kInit, int kP>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
+{
+    step_body<kInit, kP>(p);
+}
+
+// Per-wave LDS offsets of the single-pass, two-player, private-constants configuration: the same formulas as
+// the host's layout() below, as a constexpr so that a kernel specialised for one layout size can fold them.
+struct FixedLayout {
+    uint32_t off_pl, off_x, off_sum, off_cur, off_flags, off_terr, off_list, off_tail, off_tile, stride;
+};
+constexpr uint32_t up16c(uint32_t v) { return (v + 15u) & ~15u; }
+constexpr FixedLayout fixed_layout(uint32_t C, uint32_t wpw)
+{
+    FixedLayout f{};
+    const uint32_t P = 2, F = 5 * P + 16;
+    f.off_pl = up16c(wpw * C * 4);
+    f.off_x = f.off_pl + up16c(wpw * P * 8);
+    f.off_sum = f.off_x;
+    f.off_cur = f.off_sum + up16c(2u * wpw * 4u);
+    f.off_flags = f.off_cur + up16c(wpw * C);
+    f.off_terr = f.off_flags + 64u;
+    f.off_list = f.off_terr + up16c(C);
+    f.off_tail = f.off_list + up16c(wpw * C * 2u);
+    f.off_tile = f.off_tail;
+    f.stride = f.off_tile + ((wpw * P * C * F + 255u) & ~255u);
+    return f;
+}
+
+// The step for ONE layout size known at compile time (two players, kC cells, kW worlds per wave, single-pass encode,
+// private constants): every size-dependent kernel argument is replaced by a constant, so divisions by the cell count,
+// loop trip counts and LDS offsets fold (the kernel is bound by instruction issue, not by bytes: section 4.1 of
+// DESIGN.md).  The host launches it only when the simulator's parameters are exactly these; results are identical.
+template <int kC, int kW, int kWidth, int kPots>
+__device__ __forceinline__ StepParams fixed_params(const StepParams &p)
+{
+    constexpr FixedLayout f = fixed_layout(kC, kW);
+    StepParams q = p;
+    q.P = 2;
+    q.C = kC;
+    q.W = kWidth;
+    q.F = 26;
+    q.deltas = (uint64_t)(uint8_t)(int8_t)(-kWidth) | ((uint64_t)(uint8_t)(int8_t)kWidth << 8) | (1ull << 16) | (0xFFull << 24);
+    q.num_pots = kPots;
+    q.rows = 2 * kC;
+    q.block_bytes = 2 * kC * 26;
+    q.inv_c = (uint32_t)((1ull << 32) / (uint64_t)kC) + 1u;
+    q.inv_p = (uint32_t)((1ull << 32) / 2ull) + 1u;
+    q.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)(2 * kC)) + 1u;
+    q.wpw = kW;
+    q.wpp = 0;
+    q.whole = 1;
+    q.patch = 1;
+    q.share = 0;
+    q.steady = 0;
+    q.tail_even = 1;
+    q.private_consts = 1;
+    q.prio_mode = 0;
+    q.actions64 = nullptr;
+    q.terr_entries = kW * 2 * kC;
+    q.off_pl = f.off_pl;
+    q.off_x = f.off_x;
+    q.off_sum = f.off_sum;
+    q.off_cur = f.off_cur;
+    q.off_flags = f.off_flags;
+    q.off_terr = f.off_terr;
+    q.off_list = f.off_list;
+    q.off_tail = f.off_tail;
+    q.off_tile = f.off_tile;
+    q.lds_wave_stride = f.stride;
+    return q;
+}
+
+template <int kC, int kW, int kWidth, int kPots>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(const StepParams p)
+{
+    step_body<false, 2>(fixed_params<kC, kW, kWidth, kPots>(p));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Random-policy rollout on the device: num_steps steps in ONE launch.
 // The reference's random-policy harness draws `randint(high=6)` per agent per step with torch and
@@ -1159,9 +1238,8 @@ __host__ __device__ __forceinline__ uint32_t mrl_random_action(uint64_t seed, ui
 }
 
 template <int kP>
-__global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout(const StepParams p, uint32_t num_steps, uint64_t seed,
-                                                                                 uint32_t first_step, int32_t *action_out,
-                                                                                 const int32_t *action_seq)
+__device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
+                                             int32_t *action_out, const int32_t *action_seq)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -1299,6 +1377,23 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     }
 }
 
+template <int kP>
+__global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout(const StepParams p, uint32_t num_steps, uint64_t seed,
+                                                                                 uint32_t first_step, int32_t *action_out,
+                                                                                 const int32_t *action_seq)
+{
+    rollout_body<kP>(p, num_steps, seed, first_step, action_out, action_seq);
+}
+
+// the multi-step launches for one layout size known at compile time (see mrl_overcooked_step_fixed)
+template <int kC, int kW, int kWidth, int kPots>
+__global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout_fixed(const StepParams p, uint32_t num_steps, uint64_t seed,
+                                                                                       uint32_t first_step, int32_t *action_out,
+                                                                                       const int32_t *action_seq)
+{
+    rollout_body<2>(fixed_params<kC, kW, kWidth, kPots>(p), num_steps, seed, first_step, action_out, action_seq);
+}
+
 // fallback for layouts without the single-pass encode: draw into the ACTION tensor, then an ordinary step
 __global__ void mrl_overcooked_draw_actions(int32_t *action, uint32_t players, uint32_t n, uint64_t seed, uint32_t step)
 {
@@ -1326,6 +1421,9 @@ struct OvercookedSim final : mrl_sim {
     uint32_t H = 0;
     uint32_t grid = 0, lds_bytes = 0;
     bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
+    void (*fixed_kernel)(const StepParams) = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
+    void (*fixed_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
+    const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
 
@@ -1336,6 +1434,8 @@ struct OvercookedSim final : mrl_sim {
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        else if (fixed_kernel && !a.actions64)
+            hipLaunchKernelGGL(fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (a.P == 2 && !generic)
             hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
@@ -1359,7 +1459,10 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (params.P == 2 && !generic)
+            if (fixed_rollout)
+                hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, seed,
+                                   first_step, action, (const int32_t *)nullptr);
+            else if (params.P == 2 && !generic)
                 hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
                                    params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
             else
@@ -1380,7 +1483,10 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (params.P == 2 && !generic)
+            if (fixed_rollout)
+                hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, 0ull, 0u,
+                                   action, actions);
+            else if (params.P == 2 && !generic)
                 hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
                                    params, num_steps, 0ull, 0u, action, actions);
             else
@@ -1450,7 +1556,11 @@ struct OvercookedSim final : mrl_sim {
         out[2] = lds_bytes;
         out[3] = params.wpw;
     }
-    const char *kernel_name() const override { return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>"; }
+    const char *kernel_name() const override
+    {
+        if (fixed_kernel) return fixed_name;
+        return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>";
+    }
 
     uint64_t bytes_per_world_step() const override
     {
@@ -1631,6 +1741,28 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // 30 players 564 / 521 -- with many players the redundant transition (serial in the player count, one
         // active lane) costs more than the extra waves bring, so only up to four players.
         a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= 4 && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
+        {
+            // a kernel specialised for this layout size, if there is one and the parameters are exactly what it assumes
+            auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_) {
+                const FixedLayout f = fixed_layout(C_, wpw_);
+                return a.P == 2 && !sim->generic && a.C == C_ && a.W == width_ && a.num_pots == pots_ && a.wpw == wpw_ && a.whole &&
+                       a.patch && !a.share && a.private_consts && a.prio_mode == 0 && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
+                       a.off_cur == f.off_cur && a.off_flags == f.off_flags && a.off_terr == f.off_terr && a.off_list == f.off_list &&
+                       a.off_tile == f.off_tile && a.lds_wave_stride == f.stride && !mrl::debug_get("overcooked.no_fixed", 0);
+            };
+#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                          \
+    if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_)) {                                                   \
+        sim->fixed_kernel = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_>;                                    \
+        sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                \
+        sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ">";                 \
+    }
+            // the five standard layouts: cells, worlds per wave, grid width, pots
+            MRL_FIXED(20, 8, 5, 1)   // cramped_room
+            MRL_FIXED(45, 4, 9, 2)   // asymmetric_advantages
+            MRL_FIXED(25, 4, 5, 2)   // coordination_ring, forced_coordination
+            MRL_FIXED(40, 4, 8, 2)   // counter_circuit
+#undef MRL_FIXED
+        }
         const uint32_t waves = a.share ? N * kWavesPerBlock : (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
