@@ -19,6 +19,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
+    "overcooked.split",      // 1: encode and stream a group in two halves (measured slower; experiment)
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size
     "overcooked.prio",       // experiment: raise the priority of half of the waves (see overcooked.hip)
     "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do

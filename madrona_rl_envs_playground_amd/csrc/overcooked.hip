@@ -103,6 +103,7 @@ struct StepParams {
     uint32_t starts_w;        // start cells of the first four players, one byte each
     uint32_t off_terr;        // per-wave terrain copy (private_consts)
     uint32_t prio_mode;    // experiment knob (mrl_debug_set overcooked.prio): which waves run at raised priority
+    uint32_t split;        // the single step encodes and streams a group in two halves (half a slab = whole 16-byte chunks)
     uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
     const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
     uint32_t terr_entries;     // wpw * rows
@@ -555,12 +556,12 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
 // All LDS reads are issued before the first ballot (a loop that reads, votes and writes per 64 cells paid
 // one LDS round trip per iteration: 0.5 us for three iterations with four waves per SIMD).
 __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint32_t *s_obj, const uint8_t *s_cur, uint16_t *s_list,
-                                                 uint32_t nw, uint32_t lane)
+                                                 uint32_t l0, uint32_t nl, uint32_t lane)
 {
-    const uint32_t ncells = nw * p.C;
+    const uint32_t ncells = (l0 + nl) * p.C;  // cells [l0 * C, ncells): worlds l0 .. l0 + nl - 1 of the group
     constexpr int kBatch = 4;
     uint32_t ndyn = 0;
-    for (uint32_t i0 = 0; i0 < ncells; i0 += kBatch * kWave) {
+    for (uint32_t i0 = l0 * p.C; i0 < ncells; i0 += kBatch * kWave) {
         uint32_t o[kBatch], who[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
@@ -589,9 +590,11 @@ __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint
 template <int kP, bool kRestore>
 __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags, uint8_t *s_prev,
-                                              const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t nw,
-                                              uint32_t lane)
+                                              const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t l0,
+                                              uint32_t nl, uint32_t lane)
 {
+    // worlds l0 .. l0 + nl - 1 of the group (the single step encodes a group in two halves so that the first
+    // half's stores are on their way while the second is still being patched); `tile` is the whole group's
     const uint32_t C = p.C, F = p.F, shift = 5 * P;
 #ifdef MRL_DIAG
     if (p.ablate & 8u) return;  // diagnostic build: no encode at all
@@ -629,17 +632,17 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     // urgency channel (sim.cpp:79-83) of the rows that were not patched: only where a world's flag differs from
     // what the tile holds (a fresh tile holds 0); the flag changes twice per episode
     {
-        const uint32_t mine = lane < nw ? s_flags[lane] : 0u;
-        const uint32_t had = (kRestore && lane < nw) ? s_prev[lane] : 0u;
+        const uint32_t mine = lane < nl ? s_flags[l0 + lane] : 0u;
+        const uint32_t had = (kRestore && lane < nl) ? s_prev[l0 + lane] : 0u;
         if (__ballot(mine != had) != 0ull) {
-            const uint32_t nrows = nw * p.rows;
-            for (uint32_t r = lane; r < nrows; r += kWave) {
+            const uint32_t nrows = (l0 + nl) * p.rows;
+            for (uint32_t r = l0 * p.rows + lane; r < nrows; r += kWave) {
                 const uint32_t l = __umulhi(r, p.inv_rows);
                 const uint32_t f = s_flags[l];
                 if (f != (kRestore ? (uint32_t)s_prev[l] : 0u)) tile[__umul24(r, F) + F - 1u] = (uint8_t)f;
             }
             wave_lds_sync();
-            if (kRestore && lane < nw) s_prev[lane] = (uint8_t)mine;
+            if (kRestore && lane < nl) s_prev[l0 + lane] = (uint8_t)mine;
         }
     }
     wave_lds_sync();
@@ -648,10 +651,10 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 #endif
     // stream the slab out: 16-byte body as raw buffer stores over exactly the body (chunks past its end are
     // dropped by the bounds check, so the four-deep batches need no per-lane branches), then the odd tail bytes
-    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
-    const uint32_t nbytes = nw * p.block_bytes;
+    uint8_t *gobs = p.obs + (size_t)(w0 + l0) * p.block_bytes;
+    const uint32_t nbytes = nl * p.block_bytes;
     const uint32_t body = nbytes >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile + __umul24(l0, p.block_bytes));
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs, 0, (int)(body << 4), 0x00020000);
     // (reads past the body stay inside the workgroup's LDS or return zero; their stores are dropped by the bounds check)
     uint32_t k0 = lane;
@@ -665,7 +668,7 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     }
     for (; k0 < body + lane; k0 += kWave) stream_store_rsrc(out, k0 << 4, src[k0]);
     const uint32_t done_bytes = body << 4;
-    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = reinterpret_cast<const uint8_t *>(src)[done_bytes + lane];
     if constexpr (kRestore) {
         wave_lds_sync();
         for (uint32_t j = lane; j < ndyn; j += kWave) {
@@ -985,9 +988,17 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
         if (p.patch) {
-            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, nw, lane);
+            // (mrl_debug_set overcooked.split: two halves, so that the first half's stores go out while the second is
+            // patched.  Measured slower, 8.6 vs 8.25 us: hipcc waits for the first half's stores before it reuses their
+            // data registers, which serialises the halves.  Off by default.)
+            const uint32_t first = (p.split && nw > (p.wpw >> 1)) ? p.wpw >> 1 : nw;
+            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, first, lane);
             STAMP(4);
-            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, nw, lane);
+            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, first, lane);
+            if (first < nw) {
+                const uint32_t more = find_dynamic(p, s_obj, s_cur, s_list, first, nw - first, lane);
+                observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, more, s_tile, P, w0, first, nw - first, lane);
+            }
             STAMP(5);
         } else
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
@@ -1193,6 +1204,7 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     q.wpw = kW;
     q.wpp = 0;
     q.whole = 1;
+    q.split = (kW >= 2 && ((kW / 2) * 2 * kC * 26) % 16 == 0) ? p.split : 0u;
     q.patch = 1;
     q.share = 0;
     q.steady = 0;
@@ -1357,8 +1369,8 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         wave_lds_sync();
         if (p.patch) {
             // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
-            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, nw, lane);
-            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, nw, lane);
+            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
+            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
         } else {
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
@@ -1693,6 +1705,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
             // with a background image the slab must start on a 16-byte boundary in every group
             a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave && wpw * a.block_bytes < 65536u) ? 1u : 0u;
+            a.split = (a.patch && wpw >= 2 && ((wpw / 2) * a.block_bytes) % 16u == 0 && mrl::debug_get("overcooked.split", 0)) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 // with a.patch the tile is zeroed in whole 256-byte pieces (tile_zero_addtid)
