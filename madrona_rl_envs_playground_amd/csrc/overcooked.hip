@@ -1211,7 +1211,6 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     q.tail_even = 1;
     q.private_consts = 1;
     q.prio_mode = 0;
-    q.actions64 = nullptr;
     q.terr_entries = kW * 2 * kC;
     q.off_pl = f.off_pl;
     q.off_x = f.off_x;
@@ -1446,7 +1445,7 @@ struct OvercookedSim final : mrl_sim {
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
-        else if (fixed_kernel && !a.actions64)
+        else if (fixed_kernel)
             hipLaunchKernelGGL(fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (a.P == 2 && !generic)
             hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);

@@ -260,7 +260,7 @@ __device__ __forceinline__ void lds_store_tail10_bytes(uint8_t *ptr, const Tail1
 constexpr int kTerrPosPerLane = 4;  // rows of one world <= 2 * 100
 
 template <bool kInit, int kP>
-__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimpleParams p)
+__device__ __forceinline__ void step_body(const SimpleParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -452,6 +452,40 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
     }
 }
 
+template <bool kInit, int kP>
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimpleParams p)
+{
+    step_body<kInit, kP>(p);
+}
+
+// The two-player step for ONE layout size known at compile time (kC cells in rows of kWidth, kPots pots, kW worlds
+// per wave): every size-dependent kernel argument becomes a constant, so divisions by the cell count, loop trip counts
+// and LDS offsets fold -- the kernel is bound by instruction issue, not by bytes.  Launched only when
+// the simulator's parameters are exactly these; results are identical.
+constexpr uint32_t up16c(uint32_t v) { return (v + 15u) & ~15u; }
+template <int kC, int kW, int kWidth, int kPots>
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const SimpleParams p)
+{
+    SimpleParams q = p;
+    q.P = 2;
+    q.C = kC;
+    q.W = kWidth;
+    q.F = 20;
+    q.deltas = pack_deltas(kWidth);
+    q.rows = 2 * kC;
+    q.block_bytes = 2 * kC * 20;
+    q.inv_c = (uint32_t)((1ull << 32) / (uint64_t)kC) + 1u;
+    q.inv_rows = (uint32_t)((1ull << 32) / (uint64_t)(2 * kC)) + 1u;
+    q.wpw = kW;
+    q.num_pots = kPots;
+    q.off_pl = up16c(kW * kC * 4);
+    q.off_cur = q.off_pl + up16c(kW * 2 * 8);
+    q.off_list = q.off_cur + up16c(kW * kC);
+    q.off_tile = q.off_list + up16c(kW * kC * 2 > 128 ? kW * kC * 2 : 128);
+    q.lds_wave_stride = q.off_tile + up16c(kW * 2 * kC * 20) + 48u;
+    step_body<false, 2>(q);
+}
+
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,6 +504,8 @@ __global__ void fill_i32(int32_t *dst, int32_t value, size_t count)
 struct SimplecookedSim final : mrl_sim {
     SimpleParams params{};
     uint32_t H = 0, grid = 0, lds_bytes = 0;
+    void (*fixed_kernel)(const SimpleParams) = nullptr;  // mrl_simplecooked_step_fixed<...> when the parameters are exactly its
+    const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
 
@@ -480,6 +516,8 @@ struct SimplecookedSim final : mrl_sim {
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
             else
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        } else if (fixed_kernel) {
+            hipLaunchKernelGGL(fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else if (a.P == 2) {
             hipLaunchKernelGGL((mrl_simplecooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else {
@@ -574,7 +612,11 @@ struct SimplecookedSim final : mrl_sim {
         out[2] = lds_bytes;
         out[3] = params.wpw;
     }
-    const char *kernel_name() const override { return params.P == 2 ? "mrl_simplecooked_step<false, 2>" : "mrl_simplecooked_step<false, 1>"; }
+    const char *kernel_name() const override
+    {
+        if (fixed_kernel) return fixed_name;
+        return params.P == 2 ? "mrl_simplecooked_step<false, 2>" : "mrl_simplecooked_step<false, 1>";
+    }
 
     uint64_t bytes_per_world_step() const override
     {
@@ -681,6 +723,18 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.off_tile = a.off_list + up16(std::max(wpw * a.C * 2u, 128u));
         a.lds_wave_stride = a.off_tile + up16(wpw * a.block_bytes) + 48u;
         sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
+#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                                          \
+    if (!sim->fixed_kernel && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ &&                       \
+        !mrl::debug_get("overcooked.no_fixed", 0)) {                                                                                 \
+        sim->fixed_kernel = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_>;                                                   \
+        sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ">";                                \
+    }
+        // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave
+        MRL_FIXED(20, 8, 5, 1)   // simple
+        MRL_FIXED(45, 4, 9, 2)   // unident_s
+        MRL_FIXED(25, 8, 5, 2)   // random0, random1
+        MRL_FIXED(40, 4, 8, 2)   // random3
+#undef MRL_FIXED
         if (sim->lds_bytes > 65536) {
             set_error("simplecooked: internal: %u bytes of LDS per workgroup", sim->lds_bytes);
             throw HipError{MRL_ERR_INVALID};
