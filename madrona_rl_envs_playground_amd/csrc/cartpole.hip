@@ -115,13 +115,21 @@ constexpr int kUnroll = 4;  // worlds per thread whose loads are in flight toget
 // multiple of kBlock, and walks it kBlock worlds at a time -- kUnroll rounds per trip with all
 // their loads issued before the first is used (a one-round-per-trip loop keeps one 16-byte load
 // per lane in flight and measured 10.9 us per launch at 1M worlds, i.e. latency-bound).
+//
+// Finished worlds are also appended (in arrival order, one LDS atomic each) to the workgroup's
+// slice of `finished_list`, so that the reset launch touches only them instead of re-reading
+// every done flag: with ~5 % of the worlds finishing per step that launch went 7.8 -> 3.x us
+// at 1M worlds.  Episode numbers stay in ascending world order: the reset launch ranks the
+// entries of a slice by world index.
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
                                                             float4 *__restrict__ state, float *__restrict__ reward,
-                                                            int32_t *__restrict__ done, uint32_t *__restrict__ block_counts)
+                                                            int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
+                                                            uint32_t *__restrict__ finished_list)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_finished;
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
-    uint32_t finished = 0;
+    if (threadIdx.x == 0) s_finished = 0;
+    mrl::lds_barrier();
     for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += kUnroll * kBlock) {
         float4 s[kUnroll];
         int32_t a[kUnroll];
@@ -140,58 +148,72 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t
                 state[i] = s[u];
                 reward[i] = 1.f;
                 done[i] = over ? 1 : 0;
-                finished += over ? 1u : 0u;
+                if (over) finished_list[first + atomicAdd(&s_finished, 1u)] = i;  // < chunk entries: one per world
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < kBlock / 64; w++) total += s_wave[w];
-        block_counts[blockIdx.x] = total;
-    }
+    mrl::lds_barrier();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_finished;
 }
 
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_t chunk, const int32_t *__restrict__ done,
                                                              float4 *__restrict__ state,
                                                              const uint32_t *__restrict__ block_counts,
+                                                             const uint32_t *__restrict__ finished_list,
                                                              const uint32_t *__restrict__ episode_base,
                                                              uint32_t *__restrict__ next_counter,
                                                              uint32_t *__restrict__ reset_count)
 {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
+    __shared__ uint32_t s_list[kBlock];
     const bool last_block = blockIdx.x == gridDim.x - 1;
-    if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
+    const uint32_t mine = block_counts[blockIdx.x];
+    if (mine == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
-    // done flags of the first rounds are requested before the prefix is summed
-    int32_t flag[kUnroll];
+    const bool listed = mine <= (uint32_t)kBlock;  // uniform: the short list is ranked in LDS
+    // the list entry (or the done flags of the first rounds) is requested before the prefix is summed
+    uint32_t entry = ~0u;
+    int32_t flag[kUnroll] = {};
+    if (listed) {
+        if (threadIdx.x < mine) entry = finished_list[first + threadIdx.x];
+    } else {
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-        const uint32_t i = first + u * kBlock + threadIdx.x;
-        flag[u] = i < last ? done[i] : 0;
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t i = first + u * kBlock + threadIdx.x;
+            flag[u] = i < last ? done[i] : 0;
+        }
     }
     uint32_t grand_total = 0;
     uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
     const uint32_t base = *episode_base;
-    uint32_t round = 0;
-    for (uint32_t i0 = first; i0 < last; i0 += kBlock, round++) {  // uniform trip count
-        const uint32_t i = i0 + threadIdx.x;
-        int32_t f = 0;
-        if (round < (uint32_t)kUnroll) {
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) f = round == (uint32_t)u ? flag[u] : f;
-        } else {
-            f = i < last ? done[i] : 0;
+    if (listed) {
+        // rank = entries of this slice with a smaller world index (the slice is in arrival order)
+        s_list[threadIdx.x] = entry;
+        mrl::lds_barrier();
+        if (threadIdx.x < mine) {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < mine; j++) rank += s_list[j] < entry ? 1u : 0u;
+            state[entry] = fresh_state(base + running + rank);
         }
-        const bool over = f != 0;
-        uint32_t total;
-        const uint32_t rank = block_rank(over, s_wave, total);
-        if (over) state[i] = fresh_state(base + running + rank);
-        running += total;
-        __syncthreads();  // s_wave is reused by the next round
+    } else {
+        uint32_t round = 0;
+        for (uint32_t i0 = first; i0 < last; i0 += kBlock, round++) {  // uniform trip count
+            const uint32_t i = i0 + threadIdx.x;
+            int32_t f = 0;
+            if (round < (uint32_t)kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) f = round == (uint32_t)u ? flag[u] : f;
+            } else {
+                f = i < last ? done[i] : 0;
+            }
+            const bool over = f != 0;
+            uint32_t total;
+            const uint32_t rank = block_rank(over, s_wave, total);
+            if (over) state[i] = fresh_state(base + running + rank);
+            running += total;
+            __syncthreads();  // s_wave is reused by the next round
+        }
     }
     if (last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
@@ -410,6 +432,7 @@ struct CartpoleSim final : mrl_sim {
     float4 *state = nullptr;
     float *reward = nullptr;
     uint32_t *block_counts = nullptr;
+    uint32_t *finished_list = nullptr;  // [num_worlds]: per-workgroup slices of finished world indices
     uint32_t chunk = 0;  // worlds per workgroup
     uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
     uint32_t *reset_count = nullptr;
@@ -484,7 +507,7 @@ struct CartpoleSim final : mrl_sim {
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
         hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk,
-                           actions ? actions : action, state, reward, done, block_counts);
+                           actions ? actions : action, state, reward, done, block_counts, finished_list);
         MRL_HIP(hipGetLastError());
     }
 
@@ -492,7 +515,7 @@ struct CartpoleSim final : mrl_sim {
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
         hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, state,
-                           block_counts, base, counter + (parity ^ 1u), reset_count);
+                           block_counts, finished_list, base, counter + (parity ^ 1u), reset_count);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -559,6 +582,7 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->state = sim->arena.alloc<float4>(num_worlds);
         sim->reward = sim->arena.alloc<float>(num_worlds);
         sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        sim->finished_list = sim->arena.alloc<uint32_t>((size_t)sim->grid * sim->chunk);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         {

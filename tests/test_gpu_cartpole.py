@@ -75,6 +75,41 @@ def test_lockstep_vs_oracle(n, steps, hip_lib, oracle_lib):
     assert resets > 0
 
 
+@pytest.mark.parametrize("n,pattern", [(300001, "all"), (300001, "dense_block"), (1 << 20, "sparse"), (777, "all")])
+def test_planted_terminations_take_episodes_in_world_order(n, pattern, hip_lib, oracle_lib):
+    """The reset launch ranks a workgroup's short list of finished worlds in LDS and falls back to
+    the done-flag walk when more than 256 worlds of one workgroup finish at once: plant both."""
+    rng = np.random.default_rng(5)
+    sim, orc = make(n), oracle_lib.CartpoleOracle(n, num_threads=8)
+    st = sim.observation_tensor().to_torch()
+    planted = orc.state.copy()
+    if pattern == "all":
+        hit = np.ones(n, bool)
+    elif pattern == "dense_block":  # one workgroup's whole chunk, plus a sprinkle elsewhere
+        hit = rng.random(n) < 0.01
+        hit[1024:1600] = True
+    else:
+        hit = rng.random(n) < 0.03
+    planted[hit, 0] = np.where(rng.random(int(hit.sum())) < 0.5, 3.0, -3.0)  # beyond X_THRESHOLD: done whatever the action
+    orc.state[:] = planted
+    st.copy_(torch.from_numpy(planted).cuda())
+    for t in range(3):  # the re-seeded worlds keep going; later steps use the short-list path again
+        a = torch.randint(0, 2, (n, 1), dtype=torch.int32)
+        orc.step(a.numpy())
+        sim.action_tensor().to_torch().copy_(a.cuda())
+        sim.step()
+        done_gpu = sim.reset_tensor().to_torch().cpu().numpy()[:, 0]
+        assert np.array_equal(done_gpu, orc.done[:, 0]), f"done flags, step {t}"
+        r = orc.done[:, 0] == 1
+        got = st.cpu().numpy()
+        assert np.array_equal(got[r].view(np.uint32), orc.state[r].view(np.uint32)), f"fresh states, step {t}"
+        assert int(sim.reset_count_tensor().to_torch().item()) == int(r.sum())
+        if t == 0:
+            assert np.array_equal(r, hit) or pattern != "all"
+        st.copy_(torch.from_numpy(orc.state).cuda())
+    sim.close()
+
+
 @pytest.mark.parametrize("n,steps", [(5000, 120), (300001, 60), (1 << 20, 25)])
 def test_two_phase_equals_single_call(n, steps, hip_lib):
     """mrl_debug_set("fused_step"): mrl_step as ONE launch (workgroups take a ticket and wait for the lower
