@@ -337,7 +337,11 @@ __device__ __forceinline__ void orbits(uint32_t (&w)[NW], uint32_t off, uint32_t
 __device__ __forceinline__ uint32_t byte_at(const uint32_t (&r)[kRecordWords], uint32_t byte) { return (r[byte >> 2] >> ((byte & 3u) * 8u)) & 0xFFu; }
 }  // namespace full_game
 
-__device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t agent)
+// kFresh: the record is a game that deal_new_game has just written (full hands, 40 cards in the deck, all
+// tokens, nothing played, discarded or hinted) -- only the ten dealt cards are read, the rest folds to
+// constants.  The re-deal launch is a serial chain on a few lanes per wave, so its length is what counts.
+template <bool kFresh>
+__device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t *enc, uint32_t agent)
 {
     using namespace full_game;
     uint32_t r[kRecordWords];
@@ -353,7 +357,7 @@ __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t ag
     }
     // bytes of a hand: cards 0..4, size 5, known colour 6..10, known rank 11..15; plausibility words 4..8
     auto hbyte = [](const uint32_t (&h)[9], uint32_t b) { return (h[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu; };
-    const uint32_t own_size = hbyte(own, H_SIZE), other_size = hbyte(other, H_SIZE);
+    const uint32_t own_size = kFresh ? (uint32_t)kHand : hbyte(own, H_SIZE), other_size = kFresh ? (uint32_t)kHand : hbyte(other, H_SIZE);
 
     uint32_t lo[kLoWords], hi[kHiWords];
 #pragma unroll
@@ -366,26 +370,26 @@ __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t ag
     for (uint32_t c = 0; c < kHand; c++) orbits(lo, c * kBpc, kBpc, c < other_size ? 1u << (hbyte(other, H_CARDS + c) & 31u) : 0u);
     orbits(lo, kOffFlags, 2, (own_size < kHand ? 1u : 0u) | (other_size < kHand ? 2u : 0u));
     // board (:92-135)
-    const uint32_t deck = min(byte_at(r, R_DECK_SIZE), 40u);
+    const uint32_t deck = kFresh ? 40u : min(byte_at(r, R_DECK_SIZE), 40u);
     orbits(lo, kOffDeck, 32, ones(min(deck, 32u)));
     orbits(lo, kOffDeck + 32, 8, deck > 32u ? ones(deck - 32u) : 0u);
     uint32_t fw = 0;
 #pragma unroll
     for (uint32_t c = 0; c < kK; c++) {
-        const uint32_t f = byte_at(r, R_FIREWORKS + c);
+        const uint32_t f = kFresh ? 0u : byte_at(r, R_FIREWORKS + c);
         fw |= (f >= 1 && f <= kRk) ? 1u << (c * kRk + f - 1) : 0u;
     }
     orbits(lo, kOffFireworks, 25, fw);
-    const uint32_t info = byte_at(r, R_INFO);
+    const uint32_t info = kFresh ? 8u : byte_at(r, R_INFO);
     const uint32_t info_now = min(info, 13u);
     const uint32_t excess = info_now > 8u ? info_now - 8u : 0u;
     orbits(lo, kOffInfo, 13, ones(info_now));
 
     // everything below is placed relative to bit 200 + excess
-    orbits(hi, 0, 3, ones(min(byte_at(r, R_LIFE), 3u)));
+    orbits(hi, 0, 3, ones(kFresh ? 3u : min(byte_at(r, R_LIFE), 3u)));
     // discards (:137-156)
 #pragma unroll
-    for (uint32_t c = 0; c < kK; c++) {
+    for (uint32_t c = 0; c < (kFresh ? 0u : kK); c++) {
         uint32_t bits = 0;
         bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 0), 3u));
         bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 1), 2u)) << 3;
@@ -394,8 +398,8 @@ __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t ag
         bits |= ones(min(byte_at(r, R_DISCARD + c * kRk + 4), 1u)) << 9;
         orbits(hi, kRelDiscard + c * 2 * kRk, 10, bits);
     }
-    // last action (:158-289)
-    {
+    // last action (:158-289); a fresh game has none (MV_INVALID, player -1: no bit set)
+    if constexpr (!kFresh) {
         const uint32_t move = byte_at(r, R_LM_MOVE);
         const int32_t lm_player = (int8_t)byte_at(r, R_LM_PLAYER);
         const uint32_t lm_color = byte_at(r, R_LM_COLOR), lm_rank = byte_at(r, R_LM_RANK), lm_index = byte_at(r, R_LM_INDEX);
@@ -422,9 +426,9 @@ __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t ag
 #pragma unroll
         for (uint32_t c = 0; c < kHand; c++) {
             const uint32_t size = i == 0 ? own_size : other_size;
-            const uint32_t plaus = i == 0 ? own[4 + c] : other[4 + c];
-            const uint32_t kcb = i == 0 ? hbyte(own, H_KCOLOR + c) : hbyte(other, H_KCOLOR + c);
-            const uint32_t kkb = i == 0 ? hbyte(own, H_KRANK + c) : hbyte(other, H_KRANK + c);
+            const uint32_t plaus = kFresh ? ~0u : (i == 0 ? own[4 + c] : other[4 + c]);
+            const uint32_t kcb = kFresh ? 0xFFu : (i == 0 ? hbyte(own, H_KCOLOR + c) : hbyte(other, H_KCOLOR + c));
+            const uint32_t kkb = kFresh ? 0xFFu : (i == 0 ? hbyte(own, H_KRANK + c) : hbyte(other, H_KRANK + c));
             const bool have = c < size;
             const uint32_t base = kRelKnow + (i * kHand + c) * (kBpc + kK + kRk);
             orbits(hi, base, kBpc, (have && ((plaus >> i) & 1u)) ? ones(kBpc) : 0u);  // sim.cpp:311: bit <i>, not bit <v>
@@ -469,6 +473,9 @@ __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t ag
     enc[26] = excess;
 }
 
+__device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t agent) { encode_agent_full_t<false>(rec, enc, agent); }
+__device__ void encode_fresh_full(const uint8_t *rec, uint32_t *enc, uint32_t agent) { encode_agent_full_t<true>(rec, enc, agent); }
+
 // kV selects the code variant: 0 = any configuration (runtime rank count), 1 = five ranks,
 // 2 = the full game (encode_agent_full)
 template <int kV>
@@ -476,6 +483,16 @@ __device__ __forceinline__ void encode_variant(const HanabiParams &p, uint8_t *r
 {
     if constexpr (kV == 2)
         encode_agent_full(rec, enc, agent);
+    else
+        encode_agent<(kV ? 5 : 0)>(p, rec, enc, agent);
+}
+
+// encode of a game straight out of deal_new_game
+template <int kV>
+__device__ __forceinline__ void encode_fresh(const HanabiParams &p, uint8_t *rec, uint32_t *enc, uint32_t agent)
+{
+    if constexpr (kV == 2)
+        encode_fresh_full(rec, enc, agent);
     else
         encode_agent<(kV ? 5 : 0)>(p, rec, enc, agent);
 }
@@ -1162,7 +1179,7 @@ __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem,
         }
         wave_lds_sync();
         STAMP(9);
-        if (lane < 2 * my_n) encode_variant<kV>(p, l.rec + (lane >> 1) * kRecStride, l.enc + lane * kEncWords, lane & 1u);
+        if (lane < 2 * my_n) encode_fresh<kV>(p, l.rec + (lane >> 1) * kRecStride, l.enc + lane * kEncWords, lane & 1u);
         wave_lds_sync();
         STAMP(10);
         for (uint32_t r = 0; r < my_n; r++) {
@@ -1198,16 +1215,31 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
     __shared__ uint8_t s_list[kWorldsPerBlock];
     const bool last_block = blockIdx.x == gridDim.x - 1;
     uint32_t running = 0, grand_total = 0;  // finished worlds before this workgroup's
+    // everything the re-deal waits for is requested in one round trip: this workgroup's count, the
+    // episode base and (when the workgroup owns a single sub-block) its worlds' done flags
+    const bool one_sub = !kAll && p.chunk == (uint32_t)kWorldsPerBlock;
+#ifdef MRL_DIAG
+    if (!kAll && p.stamps && (threadIdx.x & 63u) == 0) {
+        p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 7] = __builtin_amdgcn_s_memtime();
+        p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    const uint32_t base = kAll ? episode_base_value : *episode_base;
+    bool flag = false;
+    if (one_sub) {
+        const uint32_t local = (threadIdx.x >> 6) * kWorldsPerWave + (threadIdx.x & 63u);
+        const uint32_t world = blockIdx.x * p.chunk + local;
+        flag = (threadIdx.x & 63u) < (uint32_t)kWorldsPerWave && world < p.num_worlds && p.done[world] != 0;
+    }
     if (!kAll) {
         if (p.block_counts[blockIdx.x] == 0 && !last_block) return;  // uniform for the workgroup
         running = mrl::scan_prefix(p.block_counts, gridDim.x, blockIdx.x, s_part, last_block, &grand_total);
     }
-    const uint32_t base = kAll ? episode_base_value : *episode_base;
     if (!kAll && last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
         *next_counter = base + grand_total;
     }
-    reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running, blockIdx.x);
+    reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running, blockIdx.x, one_sub, flag);
 }
 
 // The whole step in one launch (mrl_step on one GPU): transition, then the single-launch prefix
@@ -1370,7 +1402,7 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
             wave_lds_sync();
             if (lane < 2 * mine) {
                 const uint32_t who = s_fin[wib][lane >> 1];
-                encode_variant<kV>(p, l.rec + who * kRecStride, l.enc + (who * 2 + (lane & 1u)) * kEncWords, lane & 1u);
+                encode_fresh<kV>(p, l.rec + who * kRecStride, l.enc + (who * 2 + (lane & 1u)) * kEncWords, lane & 1u);
             }
             wave_lds_sync();
             for (uint32_t j = 0; j < mine; j++) {

@@ -10,7 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
                       max_information_tokens=8, max_life_tokens=3)
 mask, act = sim.action_mask_tensor().to_torch(), sim.action_tensor().to_torch()
-for i in range(40):
+for i in range(150):
     act.copy_((torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True).to(torch.int32))
     sim.step()
 torch.cuda.synchronize()
@@ -22,14 +22,17 @@ for a in range(6):
     d = st[:, a + 1] - st[:, a]
     print(f"{names[a]:>14s} -> {names[a+1]:14s} {np.median(d):8.0f}  [{np.percentile(d,10):7.0f} .. {np.percentile(d,90):7.0f}]  {np.median(d)/2400:5.2f} us")
 full = st[(st[:, 7] > 0) & (st[:, 11] > 0)]
-rnames = {6: "records stored", 7: "prefix known", 8: "compacted", 9: "dealt", 10: "encoded", 11: "rows written"}
-print(f"re-deal part of the fused launch ({len(full)} waves of workgroups with finished worlds)")
-for a, b in zip([6, 7, 8, 9, 10], [7, 8, 9, 10, 11]):
+rnames = {7: "reset start", 8: "compacted", 9: "dealt", 10: "encoded", 11: "rows written"}
+print(f"re-deal launch ({len(full)} waves of workgroups with finished worlds; 'compacted' includes the prefix sum)")
+for a, b in zip([7, 8, 9, 10], [8, 9, 10, 11]):
     d = full[:, b] - full[:, a]
     print(f"{rnames[a]:>14s} -> {rnames[b]:14s} {np.median(d):8.0f}  [{np.percentile(d,10):7.0f} .. {np.percentile(d,90):7.0f}]  {np.median(d)/2400:5.2f} us")
 if len(full):
-    r12 = full[:, 12] / 100.0
-    print(f"re-deal ends (us after the first start): p50 {np.median(r12 - st[:, 13].min() / 100.0):.2f} max {(r12 - st[:, 13].min() / 100.0).max():.2f}")
+    rs15, r12 = full[:, 15] / 100.0, full[:, 12] / 100.0
+    t15 = st[st[:, 15] > 0][:, 15].min() / 100.0
+    print(f"re-deal wave starts (us after the first): p50 {np.median(rs15 - t15):.2f} max {(rs15 - t15).max():.2f}")
+    print(f"re-deal wave ends (us after the first start): p50 {np.median(r12 - t15):.2f} max {(r12 - t15).max():.2f}")
+    print(f"step launch end -> re-deal launch start: {t15 - st[:, 14].max() / 100.0:.2f} us")
 d = st[:, 6] - st[:, 0]
 print(f"sub-block median {np.median(d):.0f} cycles = {np.median(d)/2400:.2f} us, max {d.max()/2400:.2f} us")
 rs, re = st[:, 13] / 100.0, st[:, 14] / 100.0   # s_memrealtime: 100 MHz, common to the whole chip
