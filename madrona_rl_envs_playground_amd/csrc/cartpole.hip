@@ -116,21 +116,19 @@ constexpr int kUnroll = 4;  // worlds per thread whose loads are in flight toget
 // their loads issued before the first is used (a one-round-per-trip loop keeps one 16-byte load
 // per lane in flight and measured 10.9 us per launch at 1M worlds, i.e. latency-bound).
 //
-// Finished worlds are also appended (in arrival order, one LDS atomic each) to the workgroup's
-// slice of `finished_list`, so that the reset launch touches only them instead of re-reading
-// every done flag: with ~5 % of the worlds finishing per step that launch went 7.8 -> 3.x us
-// at 1M worlds.  Episode numbers stay in ascending world order: the reset launch ranks the
-// entries of a slice by world index.
+// Besides the int32 done flags of the RESET tensor, every wave stores the ballot of its 64 done
+// flags as one word of `finished_mask` (world i is bit i % 64 of word i / 64; a wave's worlds are
+// 64-aligned because chunk and kBlock are multiples of 64).  The reset launch reads those words
+// -- 128 bytes per 1024 worlds instead of 4 KB of flags -- and ranks the set bits with popcounts.
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
                                                             float4 *__restrict__ state, float *__restrict__ reward,
                                                             int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
-                                                            uint32_t *__restrict__ finished_list)
+                                                            unsigned long long *__restrict__ finished_mask)
 {
-    __shared__ uint32_t s_finished;
+    __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
-    if (threadIdx.x == 0) s_finished = 0;
-    mrl::lds_barrier();
-    for (uint32_t i0 = first + threadIdx.x; i0 < last; i0 += kUnroll * kBlock) {
+    uint32_t finished = 0;  // wave-uniform
+    for (uint32_t i0 = first + threadIdx.x; i0 - threadIdx.x < last; i0 += kUnroll * kBlock) {  // uniform trip count
         float4 s[kUnroll];
         int32_t a[kUnroll];
 #pragma unroll
@@ -143,77 +141,82 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t i = i0 + u * kBlock;
+            bool over = false;
             if (i < last) {
-                const bool over = advance(s[u], a[u]);
+                over = advance(s[u], a[u]);
                 state[i] = s[u];
                 reward[i] = 1.f;
                 done[i] = over ? 1 : 0;
-                if (over) finished_list[first + atomicAdd(&s_finished, 1u)] = i;  // < chunk entries: one per world
             }
+            const unsigned long long votes = __ballot(over);
+            const uint32_t word = (i - (threadIdx.x & 63u)) >> 6;  // wave-uniform
+            if ((threadIdx.x & 63u) == 0 && i < last) finished_mask[word] = votes;
+            finished += (uint32_t)__popcll(votes);
         }
     }
-    mrl::lds_barrier();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_finished;
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) total += s_wave[w];
+        block_counts[blockIdx.x] = total;
+    }
 }
 
-__global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_t chunk, const int32_t *__restrict__ done,
-                                                             float4 *__restrict__ state,
+constexpr uint32_t kTripWords = 64;  // mask words (64 worlds each) the reset launch compacts per trip
+
+// The finished worlds of a trip are first compacted into s_list in ascending world order (entry e
+// is the e-th finished world, so its episode is base + running + e), then re-seeded one per
+// thread: the seed hash is ~150 dependent instructions, so it runs once on dense lanes rather
+// than once per mask word on the few lanes whose bit is set.
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_t chunk, float4 *__restrict__ state,
                                                              const uint32_t *__restrict__ block_counts,
-                                                             const uint32_t *__restrict__ finished_list,
+                                                             const unsigned long long *__restrict__ finished_mask,
                                                              const uint32_t *__restrict__ episode_base,
                                                              uint32_t *__restrict__ next_counter,
                                                              uint32_t *__restrict__ reset_count)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
-    __shared__ uint32_t s_list[kBlock];
+    __shared__ unsigned long long s_word[kTripWords];
+    __shared__ uint32_t s_before[kTripWords];
+    __shared__ uint32_t s_total;
+    __shared__ uint16_t s_list[kTripWords * 64];
     const bool last_block = blockIdx.x == gridDim.x - 1;
     const uint32_t mine = block_counts[blockIdx.x];
-    if (mine == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
-    const bool listed = mine <= (uint32_t)kBlock;  // uniform: the short list is ranked in LDS
-    // the list entry (or the done flags of the first rounds) is requested before the prefix is summed
-    uint32_t entry = ~0u;
-    int32_t flag[kUnroll] = {};
-    if (listed) {
-        if (threadIdx.x < mine) entry = finished_list[first + threadIdx.x];
-    } else {
-#pragma unroll
-        for (int u = 0; u < kUnroll; u++) {
-            const uint32_t i = first + u * kBlock + threadIdx.x;
-            flag[u] = i < last ? done[i] : 0;
-        }
-    }
+    const uint32_t words = (last - first + 63u) >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the first trip's mask words are requested before the prefix is summed
+    unsigned long long word = threadIdx.x < min(words, kTripWords) ? finished_mask[(first >> 6) + threadIdx.x] : 0ull;
+    if (mine == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     uint32_t grand_total = 0;
     uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
     const uint32_t base = *episode_base;
-    if (listed) {
-        // rank = entries of this slice with a smaller world index (the slice is in arrival order)
-        s_list[threadIdx.x] = entry;
-        mrl::lds_barrier();
-        if (threadIdx.x < mine) {
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < mine; j++) rank += s_list[j] < entry ? 1u : 0u;
-            state[entry] = fresh_state(base + running + rank);
-        }
-    } else {
-        uint32_t round = 0;
-        for (uint32_t i0 = first; i0 < last; i0 += kBlock, round++) {  // uniform trip count
-            const uint32_t i = i0 + threadIdx.x;
-            int32_t f = 0;
-            if (round < (uint32_t)kUnroll) {
-#pragma unroll
-                for (int u = 0; u < kUnroll; u++) f = round == (uint32_t)u ? flag[u] : f;
-            } else {
-                f = i < last ? done[i] : 0;
+    for (uint32_t w0 = 0; w0 < words; w0 += kTripWords) {  // uniform trip count
+        const uint32_t here = min(words - w0, kTripWords);
+        if (wave == 0) {
+            if (w0 > 0) word = lane < here ? finished_mask[(first >> 6) + w0 + lane] : 0ull;
+            const uint32_t c = (uint32_t)__popcll(word);
+            uint32_t x = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off, 64);
+                x += lane >= (uint32_t)off ? y : 0u;
             }
-            const bool over = f != 0;
-            uint32_t total;
-            const uint32_t rank = block_rank(over, s_wave, total);
-            if (over) state[i] = fresh_state(base + running + rank);
-            running += total;
-            __syncthreads();  // s_wave is reused by the next round
+            s_word[lane] = word;
+            s_before[lane] = x - c;
+            if (lane == 63) s_total = x;
         }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t k = wave; k < here; k += kBlock / 64) {  // one wave per word, lane = bit
+            const unsigned long long m = s_word[k];
+            if ((m >> lane) & 1ull) s_list[s_before[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((k << 6) + lane);
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < total; e += kBlock)
+            state[first + (w0 << 6) + s_list[e]] = fresh_state(base + running + e);
+        running += total;
+        __syncthreads();  // s_word / s_before / s_list are rewritten by the next trip
     }
     if (last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
@@ -432,7 +435,7 @@ struct CartpoleSim final : mrl_sim {
     float4 *state = nullptr;
     float *reward = nullptr;
     uint32_t *block_counts = nullptr;
-    uint32_t *finished_list = nullptr;  // [num_worlds]: per-workgroup slices of finished world indices
+    unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
     uint32_t chunk = 0;  // worlds per workgroup
     uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
     uint32_t *reset_count = nullptr;
@@ -507,15 +510,15 @@ struct CartpoleSim final : mrl_sim {
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
         hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk,
-                           actions ? actions : action, state, reward, done, block_counts, finished_list);
+                           actions ? actions : action, state, reward, done, block_counts, finished_mask);
         MRL_HIP(hipGetLastError());
     }
 
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
-        hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, state,
-                           block_counts, finished_list, base, counter + (parity ^ 1u), reset_count);
+        hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, state, block_counts,
+                           finished_mask, base, counter + (parity ^ 1u), reset_count);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -582,7 +585,7 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->state = sim->arena.alloc<float4>(num_worlds);
         sim->reward = sim->arena.alloc<float>(num_worlds);
         sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
-        sim->finished_list = sim->arena.alloc<uint32_t>((size_t)sim->grid * sim->chunk);
+        sim->finished_mask = sim->arena.alloc<unsigned long long>(((size_t)sim->grid * sim->chunk + 63) / 64);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         {

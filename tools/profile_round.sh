@@ -22,7 +22,13 @@ cd $root
 bash tools/pmc_passes.sh overcooked 32768 $out/${tag}_pmc
 python tools/pmc_summary.py $out/${tag}_pmc --match mrl_overcooked_step > $out/${tag}_overcooked_pmc.txt
 python tools/stamps.py > $out/${tag}_overcooked_wave_timeline.txt 2>&1
+python tools/stamps_hanabi.py > $out/${tag}_hanabi_wave_timeline.txt 2>&1
 python tools/bench_games.py > $out/${tag}_games.json
+cd /tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_hanabi_kt -o kt -- python3 $root/tools/prof_step.py --game hanabi --worlds 65536 --steps 300 > $out/${tag}_hanabi_kt.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_cartpole_kt -o kt -- python3 $root/tools/prof_step.py --game cartpole --worlds 1048576 --steps 300 > $out/${tag}_cartpole_kt.log 2>&1
+cd $root
+echo "game traces done"
 python tools/scaling_tables.py > $out/${tag}_scaling_tables.json 2>/dev/null
 python tools/mappo_rollout_loop.py > $out/${tag}_mappo_rollout_loop.json
 echo "all done"
