@@ -1225,10 +1225,13 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     return q;
 }
 
-template <int kC, int kW, int kWidth, int kPots>
+// kI64: the launch of mrl_step_with_actions_i64 (the int32 one drops the branch on the action pointer too)
+template <int kC, int kW, int kWidth, int kPots, bool kI64 = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(const StepParams p)
 {
-    step_body<false, 2>(fixed_params<kC, kW, kWidth, kPots>(p));
+    StepParams q = fixed_params<kC, kW, kWidth, kPots>(p);
+    if (!kI64) q.actions64 = nullptr;
+    step_body<false, 2>(q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1433,6 +1436,7 @@ struct OvercookedSim final : mrl_sim {
     uint32_t grid = 0, lds_bytes = 0;
     bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
     void (*fixed_kernel)(const StepParams) = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
+    void (*fixed_kernel_i64)(const StepParams) = nullptr;
     void (*fixed_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
@@ -1446,7 +1450,7 @@ struct OvercookedSim final : mrl_sim {
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (fixed_kernel)
-            hipLaunchKernelGGL(fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL(a.actions64 ? fixed_kernel_i64 : fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (a.P == 2 && !generic)
             hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
@@ -1765,8 +1769,9 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
 #define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                          \
     if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_)) {                                                   \
         sim->fixed_kernel = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_>;                                    \
+        sim->fixed_kernel_i64 = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, true>;                          \
         sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                \
-        sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ">";                 \
+        sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", false>";                 \
     }
             // the five standard layouts: cells, worlds per wave, grid width, pots
             MRL_FIXED(20, 8, 5, 1)   // cramped_room

@@ -463,10 +463,13 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
 // and LDS offsets fold -- the kernel is bound by instruction issue, not by bytes.  Launched only when
 // the simulator's parameters are exactly these; results are identical.
 constexpr uint32_t up16c(uint32_t v) { return (v + 15u) & ~15u; }
-template <int kC, int kW, int kWidth, int kPots>
+// kSource: where the actions come from -- 0 the int32 array, 1 the caller's int64 tensor, 2 drawn in the kernel
+template <int kC, int kW, int kWidth, int kPots, int kSource = 0>
 __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const SimpleParams p)
 {
     SimpleParams q = p;
+    if (kSource != 1) q.actions64 = nullptr;
+    if (kSource != 2) q.sample = 0;
     q.P = 2;
     q.C = kC;
     q.W = kWidth;
@@ -504,7 +507,7 @@ __global__ void fill_i32(int32_t *dst, int32_t value, size_t count)
 struct SimplecookedSim final : mrl_sim {
     SimpleParams params{};
     uint32_t H = 0, grid = 0, lds_bytes = 0;
-    void (*fixed_kernel)(const SimpleParams) = nullptr;  // mrl_simplecooked_step_fixed<...> when the parameters are exactly its
+    void (*fixed_kernel[3])(const SimpleParams) = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
@@ -516,8 +519,8 @@ struct SimplecookedSim final : mrl_sim {
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
             else
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
-        } else if (fixed_kernel) {
-            hipLaunchKernelGGL(fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        } else if (fixed_kernel[0]) {
+            hipLaunchKernelGGL(fixed_kernel[a.sample ? 2 : (a.actions64 ? 1 : 0)], dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else if (a.P == 2) {
             hipLaunchKernelGGL((mrl_simplecooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else {
@@ -614,7 +617,7 @@ struct SimplecookedSim final : mrl_sim {
     }
     const char *kernel_name() const override
     {
-        if (fixed_kernel) return fixed_name;
+        if (fixed_kernel[0]) return fixed_name;
         return params.P == 2 ? "mrl_simplecooked_step<false, 2>" : "mrl_simplecooked_step<false, 1>";
     }
 
@@ -724,10 +727,12 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.lds_wave_stride = a.off_tile + up16(wpw * a.block_bytes) + 48u;
         sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
 #define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                                          \
-    if (!sim->fixed_kernel && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ &&                       \
+    if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ &&                       \
         !mrl::debug_get("overcooked.no_fixed", 0)) {                                                                                 \
-        sim->fixed_kernel = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_>;                                                   \
-        sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ">";                                \
+        sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 0>;                                             \
+        sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 1>;                                             \
+        sim->fixed_kernel[2] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 2>;                                             \
+        sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", 0>";                             \
     }
         // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave
         MRL_FIXED(20, 8, 5, 1)   // simple
