@@ -103,6 +103,7 @@ struct StepParams {
     uint32_t starts_w;        // start cells of the first four players, one byte each
     uint32_t off_terr;        // per-wave terrain copy (private_consts)
     uint32_t prio_mode;    // experiment knob (mrl_debug_set overcooked.prio): which waves run at raised priority
+    uint32_t store_policy; // multi-pass stream-out: 0 sc1 write-through, 1 plain, 2 nt (chosen by slab size; mrl_debug_set overcooked.store_policy)
     uint32_t split;        // the single step encodes and streams a group in two halves (half a slab = whole 16-byte chunks)
     uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
     const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
@@ -246,6 +247,16 @@ __device__ __forceinline__ void stream_store(uint4 *dst, const uint4 &v)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(r) : "memory");
 #endif
 #endif
+}
+
+__device__ __forceinline__ void nt_store(uint4 *dst, const uint4 &v)
+{
+    u32x4 r;
+    r.x = v.x;
+    r.y = v.y;
+    r.z = v.z;
+    r.w = v.w;
+    __builtin_nontemporal_store(r, reinterpret_cast<u32x4 *>(dst));
 }
 
 // Cell-index delta of a move (sim.cpp:185-197): NORTH -W, SOUTH +W, EAST +1, WEST -1, STAY and
@@ -469,7 +480,10 @@ __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, u
     r.y = v.y;
     r.z = v.z;
     r.w = v.w;
-    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, 16);  // aux bit 4 = sc1 (write-through)
+#ifndef MRL_WHOLE_STORE_AUX
+#define MRL_WHOLE_STORE_AUX 16
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, MRL_WHOLE_STORE_AUX);  // aux bit 4 = sc1 (write-through)
 }
 
 // Single-pass encode of a group's observation slab (small layouts; see the call site).
@@ -1127,10 +1141,22 @@ __device__ __forceinline__ void step_body(const StepParams &p)
                 const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
                 const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
                 const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
-                if (ba) stream_store(dst + ka, va);
-                if (bb) stream_store(dst + kb, vb);
-                if (bc) stream_store(dst + kc, vc);
-                if (bd) stream_store(dst + kd, vd);
+                if (p.store_policy == 0) {
+                    if (ba) stream_store(dst + ka, va);
+                    if (bb) stream_store(dst + kb, vb);
+                    if (bc) stream_store(dst + kc, vc);
+                    if (bd) stream_store(dst + kd, vd);
+                } else if (p.store_policy == 1) {
+                    if (ba) dst[ka] = va;
+                    if (bb) dst[kb] = vb;
+                    if (bc) dst[kc] = vc;
+                    if (bd) dst[kd] = vd;
+                } else {
+                    if (ba) nt_store(dst + ka, va);
+                    if (bb) nt_store(dst + kb, vb);
+                    if (bc) nt_store(dst + kc, vc);
+                    if (bd) nt_store(dst + kd, vd);
+                }
             }
         }
         const uint32_t done_bytes = head + (body << 4);
@@ -1672,6 +1698,15 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         memcpy(&a.pots_w, consts + kConstPots, 4);
         a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
         a.prio_mode = (uint32_t)mrl::debug_get("overcooked.prio", 0);
+        {
+            // Multi-pass stream-out: write-through (sc1) stores stream the slab out while the waves still work, which pays
+            // as long as the slab fits the 256 MiB Infinity Cache; larger slabs go out as plain stores through the L2
+            // write-back (same rate in general, and 30 players x 1000 worlds -- 1.27 GB in 1.27 MB strides -- ran at half
+            // the rate with write-through: 490 vs 258 us per step).
+            const int64_t knob = mrl::debug_get("overcooked.store_policy", 0);  // 0 auto, 1 sc1, 2 plain, 3 nt
+            const uint64_t slab = (uint64_t)N * a.P * a.C * a.F;
+            a.store_policy = knob ? (uint32_t)(knob - 1) : (slab > (256ull << 20) ? 1u : 0u);
+        }
         a.private_consts = (P <= 4 && num_pots <= 4 && !mrl::debug_get("overcooked.shared_consts", 0)) ? 1u : 0u;
         memcpy(&a.starts_w, consts + kConstStart, 4);
         a.wpp = a.rows <= (uint32_t)kRowsPerPass ? (uint32_t)kRowsPerPass / a.rows : 0u;

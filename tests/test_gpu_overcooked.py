@@ -108,6 +108,27 @@ def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
     sim.close()
 
 
+@pytest.mark.parametrize("policy", [1, 2, 3])
+def test_multi_pass_store_policies(policy, hip_lib, oracle_lib):
+    """Large layouts stream their rows out with write-through stores when the slab fits the Infinity Cache and with
+    plain stores above that (chosen by size at construction); the knob forces each flavour on a small batch."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params("many_player_layout", 40, max_num_players=12)
+    n, P, C = 37, 12, params["height"] * params["width"]
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    with debug_knobs({"overcooked.store_policy": policy}):
+        sim = make_sim(params, n)
+    o = world_major(sim).view(n, P, C, 5 * P + 16)
+    rng = np.random.default_rng(policy)
+    for t in range(60):
+        acts = rng.integers(0, 6, size=(P, n)).astype(np.int32)
+        orc.step(acts)
+        sim.step_with_actions(torch.from_numpy(acts).cuda().view(P, n, 1))
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward), f"reward, step {t}"
+    sim.close()
+
+
 @pytest.mark.parametrize("layout,cap,n,variant", [("cramped_room", None, 4099, 1), ("counter_circuit", None, 300, 1),
                                                    ("multiplayer_schelling", None, 257, 0), ("many_player_layout", 16, 40, 0)])
 def test_same_cell_interactions_in_player_order(layout, cap, n, variant, hip_lib, oracle_lib):
