@@ -136,7 +136,17 @@ def run(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if rehearse else "nccl"
         if rehearse:
-            dist.init_process_group("gloo")
+            # gloo's C++ side announces its connections on stdout; stdout carries the one JSON line and nothing else
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 

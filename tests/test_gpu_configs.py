@@ -165,8 +165,8 @@ def test_bench_starts_its_own_ranks(hip_lib):
     proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
                           env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, proc.stdout
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), proc.stdout  # stdout is the JSON line and nothing else
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
     assert out["ranks"] == {"world_size": 2, "backend": "gloo", "rehearsal_on_one_gpu": True}

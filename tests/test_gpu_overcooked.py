@@ -108,6 +108,44 @@ def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
     sim.close()
 
 
+@pytest.mark.parametrize("layout,n,wpw", [("cramped_room", 4099, 8), ("asymmetric_advantages", 1000, 4), ("coordination_ring", 513, 4),
+                                          ("counter_circuit", 1200, 4)])
+def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
+    """The five standard layouts run kernels specialised at compile time for their size; `overcooked.no_fixed` sends
+    the same simulator through the generic kernel.  Same actions (int32 array, int64 tensor, device-side rollout,
+    action sequence): same tensors."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params(layout, 60)
+    P = params["num_players"]
+    with debug_knobs({"overcooked.wpw": wpw}):  # the group size the library picks for these layouts from 32768 worlds on
+        fixed = make_sim(params, n)
+    with debug_knobs({"overcooked.wpw": wpw, "overcooked.no_fixed": 1}):
+        generic = make_sim(params, n)
+    assert "step_fixed<" in fixed.kernel_name and generic.kernel_name == "mrl_overcooked_step<false, 2>"
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(80):
+        if t % 4 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            fixed.step_with_actions(a)
+            generic.step_with_actions(a)
+        elif t % 4 == 1:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int64, device="cuda", generator=gen)
+            fixed.step_with_actions_i64(a)
+            generic.step_with_actions_i64(a)
+        elif t % 4 == 2:
+            fixed.rollout_random(3, seed=9, first_step=3 * t)
+            generic.rollout_random(3, seed=9, first_step=3 * t)
+        else:
+            seq = torch.randint(0, 6, (4, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            fixed.step_sequence(seq)
+            generic.step_sequence(seq)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "action_tensor", "state_objects_tensor",
+                    "state_players_tensor", "state_timestep_tensor"):
+            assert torch.equal(getattr(fixed, get)().to_torch(), getattr(generic, get)().to_torch()), f"{get}, step {t}"
+    fixed.close()
+    generic.close()
+
+
 @pytest.mark.parametrize("policy", [1, 2, 3])
 def test_multi_pass_store_policies(policy, hip_lib, oracle_lib):
     """Large layouts stream their rows out with write-through stores when the slab fits the Infinity Cache and with

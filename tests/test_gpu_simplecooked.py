@@ -95,6 +95,38 @@ def test_against_oracle(layout, horizon, cap, n, steps, p_interact, hip_lib, ora
     sim.close()
 
 
+@pytest.mark.parametrize("layout,n,wpw", [("simple", 4099, 8), ("random3", 1200, 4)])
+def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
+    """The standard layout sizes run kernels specialised at compile time; `overcooked.no_fixed` sends the same
+    simulator through the generic kernel.  Same actions (int32 array, int64 tensor, device-side draw): same tensors."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_simplecooked_layout_params(layout, 60)
+    P = params["num_players"]
+    with debug_knobs({"overcooked.wpw": wpw}):  # the group size the library picks for these layouts on large batches
+        fixed = make_sim(params, n)
+    with debug_knobs({"overcooked.wpw": wpw, "overcooked.no_fixed": 1}):
+        generic = make_sim(params, n)
+    assert "step_fixed<" in fixed.kernel_name and "step_fixed<" not in generic.kernel_name
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(90):
+        if t % 3 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            fixed.step_with_actions(a)
+            generic.step_with_actions(a)
+        elif t % 3 == 1:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int64, device="cuda", generator=gen)
+            fixed.step_with_actions_i64(a)
+            generic.step_with_actions_i64(a)
+        else:
+            fixed.rollout_random(1, seed=9, first_step=t)
+            generic.rollout_random(1, seed=9, first_step=t)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "action_tensor", "state_objects_tensor",
+                    "state_players_tensor", "state_timestep_tensor"):
+            assert torch.equal(getattr(fixed, get)().to_torch(), getattr(generic, get)().to_torch()), f"{get}, step {t}"
+    fixed.close()
+    generic.close()
+
+
 def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
     """mrl_rollout_random draws the documented stream in the step kernel; mrl_step_sequence == single steps."""
     from madrona_rl_envs_playground_amd.simulators import random_action
