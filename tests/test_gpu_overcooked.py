@@ -318,3 +318,65 @@ def test_step_sequence_equals_single_steps(layout, cap, n, steps, hip_lib):
         done_any += int(b.done_tensor().to_torch().sum().item())
     a.close()
     b.close()
+
+
+def _random_layout(rng):
+    """A random rectangular kitchen in the reference's Config format (sim.hpp:44-57): non-AIR border, sparse
+    interior walls, a few pots / sources / serving cells on border or interior wall cells, 1..6 players on AIR."""
+    H, W = int(rng.integers(3, 10)), int(rng.integers(3, 12))
+    while H * W > 255:
+        W -= 1
+    terr = np.full((H, W), 2, np.int64)                     # COUNTER
+    terr[1:-1, 1:-1] = 0                                    # AIR
+    interior = [(y, x) for y in range(1, H - 1) for x in range(1, W - 1)]
+    for (y, x) in interior:
+        if rng.random() < 0.12:
+            terr[y, x] = 2
+    walls = [(y, x) for y in range(H) for x in range(W) if terr[y, x] == 2]
+    rng.shuffle(walls)
+    kinds = [1] * int(rng.integers(1, 7)) + [3] * int(rng.integers(1, 3)) + [4] * int(rng.integers(0, 2)) + \
+            [5] * int(rng.integers(1, 3)) + [6] * int(rng.integers(1, 3))   # POT, ONION, TOMATO, DISH, SERVING
+    for k, (y, x) in zip(kinds, walls):
+        terr[y, x] = k
+    air = [(y, x) for y in range(H) for x in range(W) if terr[y, x] == 0]
+    if not air:
+        terr[1, 1] = 0
+        air = [(1, 1)]
+    P = int(min(len(air), rng.integers(1, 7)))
+    rng.shuffle(air)
+    starts = air[:P]
+    times = [int(rng.integers(1, 25)) for _ in range(16)]
+    values = [int(rng.integers(0, 40)) if rng.random() < 0.5 else 0 for _ in range(16)]
+    return dict(height=H, width=W, terrain=[int(v) for v in terr.reshape(-1)], num_players=P,
+                start_player_x=[x for (_, x) in starts], start_player_y=[y for (y, _) in starts],
+                placement_in_pot_rew=int(rng.integers(0, 6)), dish_pickup_rew=0, soup_pickup_rew=int(rng.integers(0, 8)),
+                recipe_times=times, recipe_values=values, horizon=int(rng.integers(15, 70)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_layouts_against_oracle(seed, hip_lib, oracle_lib):
+    """Kitchens nobody tuned a launch shape for: random sizes, player counts (odd ones too), pot counts beyond the
+    kernel-argument table, recipe tables and horizons; a few world counts so that every group size gets picked."""
+    rng = np.random.default_rng(1000 + seed)
+    params = _random_layout(rng)
+    n = int(rng.choice([1, 7, 64, 300, 1111, 5000, 40000 if params["num_players"] <= 2 else 9000]))
+    P, C = params["num_players"], params["height"] * params["width"]
+    F = 5 * P + 16
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    sim = make_sim(params, n)
+    o = world_major(sim).view(n, P, C, F)
+    assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"initial obs, {params} x {n}"
+    steps = 40 if n <= 5000 else 14
+    for t in range(steps):
+        acts = rng.integers(0, 5, size=(P, n)).astype(np.int32)
+        acts[rng.random((P, n)) < 0.4] = 5
+        orc.step(acts)
+        sim.step_with_actions(torch.from_numpy(acts).cuda().view(P, n, 1))
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}: {params} x {n} ({sim.kernel_name}, {sim.launch_shape})"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward), f"reward, step {t}"
+        assert np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done), f"done, step {t}"
+    pl, ob, ts = orc.dump()
+    assert np.array_equal(unpack_players(sim.state_players_tensor().to_torch()), pl)
+    assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob)
+    assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts)
+    sim.close()

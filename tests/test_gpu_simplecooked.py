@@ -224,3 +224,66 @@ def test_full_shard_properties(hip_lib, oracle_lib):
         assert np.array_equal(got, orc.obs), f"sampled worlds differ from the oracle at step {t}"
     assert total > 0
     sim.close()
+
+
+def _random_kitchen(rng):
+    """A random old-style kitchen in the reference's Config format (src/overcooked2_env/sim.hpp:40-53): at most 100
+    cells and two players; terrain codes AIR 0, POT 1, COUNTER 2, ONION 3, (TOMATO 4 is wiped by the C++), DISH 4 -> see layouts."""
+    ref = layouts.get_simplecooked_layout_params("simple", 50)
+    codes = {"pot": 1, "counter": 2, "onion": 3, "dish": ref["terrain"][16], "serve": ref["terrain"][18]}
+    H, W = int(rng.integers(3, 10)), int(rng.integers(3, 11))
+    while H * W > 100:
+        W -= 1
+    terr = np.full((H, W), codes["counter"], np.int64)
+    terr[1:-1, 1:-1] = 0
+    for y in range(1, H - 1):
+        for x in range(1, W - 1):
+            if rng.random() < 0.1:
+                terr[y, x] = codes["counter"]
+    walls = [(y, x) for y in range(H) for x in range(W) if terr[y, x] == codes["counter"]]
+    rng.shuffle(walls)
+    kinds = ["pot"] * int(rng.integers(1, 5)) + ["onion"] * int(rng.integers(1, 3)) + ["dish"] * int(rng.integers(1, 3)) + \
+            ["serve"] * int(rng.integers(1, 3))
+    for k, (y, x) in zip(kinds, walls):
+        terr[y, x] = codes[k]
+    air = [(y, x) for y in range(H) for x in range(W) if terr[y, x] == 0]
+    if not air:
+        terr[1, 1] = 0
+        air = [(1, 1)]
+    P = int(min(len(air), rng.integers(1, 3)))
+    rng.shuffle(air)
+    starts = air[:P]
+    return dict(ref, height=H, width=W, terrain=[int(v) for v in terr.reshape(-1)], num_players=P,
+                start_player_x=[x for (_, x) in starts], start_player_y=[y for (y, _) in starts],
+                placement_in_pot_rew=int(rng.integers(0, 6)), dish_pickup_rew=int(rng.integers(0, 6)),
+                soup_pickup_rew=int(rng.integers(0, 8)), horizon=int(rng.integers(15, 70)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_kitchens_against_oracle(seed, hip_lib, oracle_lib):
+    """Kitchens nobody tuned a launch shape for: random sizes, one or two players, several pots, reward shaping values
+    and horizons; a few world counts so that every group size gets picked."""
+    rng = np.random.default_rng(2000 + seed)
+    params = _random_kitchen(rng)
+    n = int(rng.choice([1, 7, 64, 300, 1111, 5000, 40000]))
+    P, C = params["num_players"], params["height"] * params["width"]
+    F = 5 * P + 10
+    orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
+    sim = make_sim(params, n)
+    o = sim.observation_world_major_tensor().to_torch().view(n, P, C, F)
+    assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"initial obs, {params} x {n}"
+    steps = 50 if n <= 5000 else 14
+    for t in range(steps):
+        acts = rng.integers(0, 5, size=(P, n)).astype(np.int32)
+        acts[rng.random((P, n)) < 0.45] = 5
+        orc.step(acts)
+        sim.step_with_actions(torch.from_numpy(acts).cuda().view(P, n, 1))
+        assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}: {params} x {n} ({sim.kernel_name}, {sim.launch_shape})"
+        assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward), f"reward, step {t}"
+        assert np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done), f"done, step {t}"
+    pl, ob, ts, dishes = orc.dump()
+    assert np.array_equal(unpack_players(sim.state_players_tensor().to_torch()), pl)
+    assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob)
+    assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts)
+    assert np.array_equal(sim.dishes_out_tensor().to_torch().cpu().numpy(), dishes)
+    sim.close()
