@@ -1434,6 +1434,164 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     rollout_body<2>(fixed_params<kC, kW, kWidth, kPots>(p), num_steps, seed, first_step, action_out, action_seq);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One step of kG consecutive groups per wave (single-pass, two-player, private-constants configurations).
+// The ordinary launch gives every group its own wave: 4096 waves at 32768 worlds, all resident at once, all in the
+// same phase at the same time, and nothing leaves the chip before a wave has gone through load latency, transition
+// and patching.  Here a wave steps group A, streams it out, and steps group B while A's stores drain: B's state was
+// requested together with A's (one latency for both), the observation tile is zeroed and given its terrain bytes
+// once -- after A's stream-out the patched rows are put back to their static content, as in the multi-step
+// launches -- and with half as many waves per SIMD a wave's phases take half as long, so the first stores leave
+// earlier.  Same state and output arrays, same results.
+// ---------------------------------------------------------------------------------------------
+template <int kP, int kG>
+__device__ __forceinline__ void groups_body(const StepParams &p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    STAMP(0);
+    STAMP_REALTIME(13);
+    const __amdgpu_buffer_rsrc_t r_terr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.consts), 0, (int)((p.C + 3u) & ~3u), 0x00020000);
+    const uint32_t terr_word = __builtin_amdgcn_raw_buffer_load_b32(r_terr, (int)(lane * 4u), 0, 0);
+    uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
+    const uint8_t *s_terrain = wbase + p.off_terr;
+    const uint8_t *s_pots = smem + kConstPots;
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t first_world = (logical_block * kWavesPerBlock + wib) * p.wpw * kG;  // this wave's kG groups are consecutive
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(wbase + p.off_x);
+    uint32_t *s_sum = reinterpret_cast<uint32_t *>(wbase + p.off_sum);
+    uint32_t *s_blk = s_sum + p.wpw;
+    uint8_t *s_cur = wbase + p.off_cur;
+    uint8_t *s_flags = wbase + p.off_flags;
+    uint8_t *s_prev = s_flags + 32;  // urgency flags as the tile holds them
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(wbase + p.off_list);
+    uint8_t *s_tile = wbase + p.off_tile;
+    const uint32_t P = (uint32_t)kP, C = p.C, N = p.num_worlds;
+    const uint32_t wl = kP == 2 ? lane >> 1 : (P == 1u ? lane : __umulhi(lane, p.inv_p));
+    const uint32_t q = lane - wl * P;
+
+    // every group's state slab is requested up front: one HBM / Infinity Cache latency for all of them
+    constexpr int kBatch = 4;
+    uint32_t cell_reg[kG][kBatch];
+    uint2 pl_reg[kG];
+    uint32_t a_raw[kG];
+    int32_t t_reg[kG];
+    // Worlds in each of the wave's groups, worked out ONCE and kept opaque (readfirstlane): re-deriving them from N
+    // inside the unrolled group loop let hipcc fold "this group is empty" (w0 >= N) into w0 == N and run a wave's
+    // second group past the end of the batch when the batch ends inside its first one (found by the ragged-batch test).
+    uint32_t nw_of[kG];
+#pragma unroll
+    for (int g = 0; g < kG; g++) {
+        const uint32_t w0 = first_world + (uint32_t)g * p.wpw;
+        nw_of[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w0 < N ? min(p.wpw, N - w0) : 0u));
+    }
+#pragma unroll
+    for (int g = 0; g < kG; g++) {
+        const uint32_t w0 = first_world + (uint32_t)g * p.wpw;
+        const uint32_t nw = nw_of[g];
+        const uint32_t wc = min(w0, N - 1u);  // empty groups read nothing (zero-sized descriptors) from a valid address
+        const __amdgpu_buffer_rsrc_t r_obj = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.cell_obj + (size_t)wc * C), 0, (int)(nw * C * 4u), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) cell_reg[g][k] = __builtin_amdgcn_raw_buffer_load_b32(r_obj, (int)((lane + (uint32_t)k * kWave) * 4u), 0, 0);
+        const __amdgpu_buffer_rsrc_t r_pl = __builtin_amdgcn_make_buffer_rsrc(p.players + (size_t)wc * P, 0, (int)(nw * P * 8u), 0x00020000);
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r_pl, (int)(lane * 8u), 0, 0);
+        pl_reg[g] = make_uint2(raw[0], raw[1]);
+        const size_t a_at = (size_t)(lane < nw * P ? q : 0u) * N + min(w0 + wl, N - 1u);
+        a_raw[g] = p.actions64 ? (uint32_t)p.actions64[a_at] : (uint32_t)p.actions[a_at];
+        t_reg[g] = p.timestep[min(w0 + wl, N - 1u)];
+    }
+    {
+        const uint32_t nw0 = nw_of[0];  // the first group is the wave's fullest
+        TerrPos tpos;
+        terrain_request(p, lane, tpos);
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        tile_zero_addtid(s_tile, nw0 * p.block_bytes);
+        if (lane < 32) s_prev[lane] = 0;
+        STAMP(6);
+        terrain_deliver(p, tpos, s_tile, nw0);
+        if (lane * 4u < p.C) reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(s_terrain))[lane] = terr_word;
+        STAMP(7);
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int g = 0; g < kG; g++) {
+        const uint32_t w0 = first_world + (uint32_t)g * p.wpw;
+        const uint32_t nw = nw_of[g];
+        if (nw == 0) break;  // wave-uniform; later groups are empty too
+        const uint32_t ncells = nw * C, nplayers = nw * P;
+        const bool active = lane < nplayers;
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = lane + k * kWave;
+            if (i < ncells) s_obj[i] = cell_reg[g][k];
+        }
+        for (uint32_t i = lane + kBatch * kWave; i < ncells; i += kWave) s_obj[i] = p.cell_obj[(size_t)w0 * C + i];
+        uint32_t posori = active ? pl_reg[g].x & 0xFFFFu : 0u, held = active ? pl_reg[g].y : (uint32_t)kItemNone;
+        const uint32_t act = (active && a_raw[g] <= A_INTERACT) ? a_raw[g] : (uint32_t)A_STAY;
+        if (p.actions64 && active) p.action_mirror[(size_t)q * N + w0 + wl] = (int32_t)a_raw[g];
+        wave_lds_sync();
+        if (g == 0) STAMP(1);
+        int32_t reward_world = 0;
+        transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
+        tick_pots(p, s_pots, s_obj, nw, lane);
+        int32_t t = t_reg[g] + 1;
+        const bool reset_now = (int64_t)t >= p.horizon;
+        if (__ballot(active && reset_now) != 0ull) {
+            if (reset_now) {
+                t = 0;
+                posori = ((p.starts_w >> (8u * (q & 3u))) & 0xFFu) | (A_NORTH << 8);
+                held = kItemNone;
+            }
+            if (active && q == 0) s_sum[wl] = reset_now ? 1u : 0u;
+            wave_lds_sync();
+            for (uint32_t i = lane; i < ncells; i += kWave)
+                if (s_sum[__umulhi(i, p.inv_c)] != 0u) s_obj[i] = kItemNone;
+            wave_lds_sync();
+        }
+        if (g == 0) STAMP(2);
+        if (active) {
+            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+        }
+        wave_lds_sync();
+        if (g == 0) STAMP(3);
+        const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
+        if (g == 0) STAMP(4);
+        observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
+        if (g == 0) STAMP(5);
+        // the group's state, rewards and flags: behind its stream-out, like the ordinary step
+        uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
+        if (active) {
+            const uint32_t world = w0 + wl;
+            p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+            p.reward[(size_t)q * N + world] = reward_world;
+            if (q == 0) {
+                p.timestep[world] = t;
+                p.done[world] = (int32_t)reset_now;
+            }
+            if (g + 1 < kG) s_cur[wl * C + (posori & 0xFFu)] = 0xFF;  // the cell -> player map starts the next group empty
+        }
+        wave_lds_sync();
+    }
+    STAMP(15);
+    STAMP_REALTIME(14);
+}
+
+template <int kC, int kW, int kWidth, int kPots, bool kI64, int kG>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_groups_fixed(const StepParams p)
+{
+    StepParams q = fixed_params<kC, kW, kWidth, kPots>(p);
+    if (!kI64) q.actions64 = nullptr;
+    groups_body<2, kG>(q);
+}
+
 // fallback for layouts without the single-pass encode: draw into the ACTION tensor, then an ordinary step
 __global__ void mrl_overcooked_draw_actions(int32_t *action, uint32_t players, uint32_t n, uint64_t seed, uint32_t step)
 {
@@ -1463,6 +1621,10 @@ struct OvercookedSim final : mrl_sim {
     bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
     void (*fixed_kernel)(const StepParams) = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
     void (*fixed_kernel_i64)(const StepParams) = nullptr;
+    void (*groups_kernel)(const StepParams) = nullptr;      // mrl_overcooked_step_groups_fixed<...>: kGroups groups per wave
+    void (*groups_kernel_i64)(const StepParams) = nullptr;
+    uint32_t groups_grid = 0;
+    const char *groups_name = nullptr;
     void (*fixed_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
@@ -1475,6 +1637,8 @@ struct OvercookedSim final : mrl_sim {
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        else if (groups_kernel)
+            hipLaunchKernelGGL(a.actions64 ? groups_kernel_i64 : groups_kernel, dim3(groups_grid), dim3(kBlock), lds_bytes, stream, a);
         else if (fixed_kernel)
             hipLaunchKernelGGL(a.actions64 ? fixed_kernel_i64 : fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (a.P == 2 && !generic)
@@ -1592,13 +1756,14 @@ struct OvercookedSim final : mrl_sim {
     size_t action_elems() const override { return (size_t)params.P * num_worlds; }
     void launch_shape(uint32_t out[4]) const override
     {
-        out[0] = grid;
+        out[0] = groups_kernel ? groups_grid : grid;
         out[1] = kBlock;
         out[2] = lds_bytes;
-        out[3] = params.wpw;
+        out[3] = params.wpw * (groups_kernel ? 2u : 1u);  // worlds a wavefront steps (two groups one after the other, or one)
     }
     const char *kernel_name() const override
     {
+        if (groups_kernel) return groups_name;
         if (fixed_kernel) return fixed_name;
         return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>";
     }
@@ -1807,7 +1972,21 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         sim->fixed_kernel_i64 = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, true>;                          \
         sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                \
         sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", false>";                 \
+        if (groups == 2) {                                                                                          \
+            sim->groups_kernel = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, false, 2>;              \
+            sim->groups_kernel_i64 = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, true, 2>;           \
+            sim->groups_name = "mrl_overcooked_step_groups_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", false, 2>"; \
+        }                                                                                                           \
     }
+            // Groups of worlds a wave steps one after the other in the single step (mrl_overcooked_step_groups_fixed).
+            // Measured on MI355X, us per launch with one / two groups per wave: cramped_room 32768 worlds (4096 groups)
+            // 8.26 / 9.34, 65536 14.7 / 14.4, 131072 26.8 / 24.9, 524288 118 / 111, 1 M 228 / 240; at 8192 groups
+            // counter_circuit 14.3 / 14.2, asymmetric_advantages 17.8 / 18.1, coordination_ring 11.0 / 11.3; counter_circuit
+            // 131072 worlds (32768 groups) 54.4 / 49.2.  So: two groups from 12288 to 65536 groups.
+            // mrl_debug_set overcooked.groups: 0 = that rule, 1 = always one, 2 = always two.
+            const int64_t groups_knob = mrl::debug_get("overcooked.groups", 0);
+            const uint64_t ngroups = ((uint64_t)N + wpw - 1) / wpw;
+            const int64_t groups = groups_knob ? groups_knob : ((ngroups >= 12288 && ngroups <= 65536) ? 2 : 1);
             // the five standard layouts: cells, worlds per wave, grid width, pots
             MRL_FIXED(20, 8, 5, 1)   // cramped_room
             MRL_FIXED(45, 4, 9, 2)   // asymmetric_advantages
@@ -1818,6 +1997,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         const uint32_t waves = a.share ? N * kWavesPerBlock : (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
+        if (sim->groups_kernel) {
+            const uint32_t gwaves = (waves + 1u) / 2u;
+            sim->groups_grid = ((gwaves + kWavesPerBlock - 1) / kWavesPerBlock + 7u) & ~7u;
+        }
 
 #ifdef MRL_DIAG
         if (mrl::debug_get("stamps", 0)) a.stamps = sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16);

@@ -146,6 +146,38 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
     generic.close()
 
 
+@pytest.mark.parametrize("layout,n,wpw", [("cramped_room", 4099, 8), ("cramped_room", 40003, 0), ("asymmetric_advantages", 16391, 0),
+                                          ("counter_circuit", 1001, 4), ("coordination_ring", 24581, 0)])
+def test_two_groups_per_wave_equals_one(layout, n, wpw, hip_lib):
+    """Mid-sized batches of the standard layouts step two consecutive groups per wave (the second group's state is
+    requested with the first's, the tile is reused): `overcooked.groups` forces either shape.  Batches that end inside
+    a wave's first group, int32 and int64 actions: same tensors as one wave per group."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params(layout, 60)
+    P = params["num_players"]
+    with debug_knobs({"overcooked.wpw": wpw, "overcooked.groups": 1}):
+        one = make_sim(params, n)
+    with debug_knobs({"overcooked.wpw": wpw, "overcooked.groups": 2}):
+        two = make_sim(params, n)
+    assert "step_fixed<" in one.kernel_name and "step_groups_fixed<" in two.kernel_name
+    assert two.launch_shape[0] < one.launch_shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(130):
+        if t % 2 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            one.step_with_actions(a)
+            two.step_with_actions(a)
+        else:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int64, device="cuda", generator=gen)
+            one.step_with_actions_i64(a)
+            two.step_with_actions_i64(a)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "action_tensor", "state_objects_tensor",
+                    "state_players_tensor", "state_timestep_tensor"):
+            assert torch.equal(getattr(one, get)().to_torch(), getattr(two, get)().to_torch()), f"{get}, step {t}"
+    one.close()
+    two.close()
+
+
 @pytest.mark.parametrize("policy", [1, 2, 3])
 def test_multi_pass_store_policies(policy, hip_lib, oracle_lib):
     """Large layouts stream their rows out with write-through stores when the slab fits the Infinity Cache and with
