@@ -102,9 +102,7 @@ struct StepParams {
                               // in a per-wave LDS copy -> no workgroup barrier in the kernel (the waves never meet)
     uint32_t starts_w;        // start cells of the first four players, one byte each
     uint32_t off_terr;        // per-wave terrain copy (private_consts)
-    uint32_t prio_mode;    // experiment knob (mrl_debug_set overcooked.prio): which waves run at raised priority
     uint32_t store_policy; // multi-pass stream-out: 0 sc1 write-through, 1 plain, 2 nt (chosen by slab size; mrl_debug_set overcooked.store_policy)
-    uint32_t split;        // the single step encodes and streams a group in two halves (half a slab = whole 16-byte chunks)
     uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
     const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
     uint32_t terr_entries;     // wpw * rows
@@ -819,16 +817,6 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     STAMP(0);
     STAMP_REALTIME(13);
     if (ABLATED(16)) return;  // diagnostic build: the empty launch
-    if (p.prio_mode) {
-        const uint32_t sel = p.prio_mode & 3u;
-        const bool fast = sel == 1 ? ((blockIdx.x >> 3) & 1u) != 0 : sel == 2 ? (wib & 1u) != 0 : ((blockIdx.x >> 4) & 1u) != 0;
-        if (fast) {
-            if (p.prio_mode & 4u)
-                __builtin_amdgcn_s_setprio(1);
-            else
-                __builtin_amdgcn_s_setprio(3);
-        }
-    }
     // the constants and the group's state slab are fetched together: one HBM/L2 latency.  Small configurations
     // (p.private_consts) need only the terrain in LDS, one private copy per wave: no barrier, the waves never meet.
     constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
@@ -1002,17 +990,11 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     const uint32_t F = p.F, shift = 5 * P;
     if (p.whole) {
         if (p.patch) {
-            // (mrl_debug_set overcooked.split: two halves, so that the first half's stores go out while the second is
-            // patched.  Measured slower, 8.6 vs 8.25 us: hipcc waits for the first half's stores before it reuses their
-            // data registers, which serialises the halves.  Off by default.)
-            const uint32_t first = (p.split && nw > (p.wpw >> 1)) ? p.wpw >> 1 : nw;
-            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, first, lane);
+            // (Encoding and streaming the group in two halves, so that the first half's stores leave while the second is
+            // patched, measured slower: 8.6 vs 8.25 us.)
+            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
             STAMP(4);
-            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, first, lane);
-            if (first < nw) {
-                const uint32_t more = find_dynamic(p, s_obj, s_cur, s_list, first, nw - first, lane);
-                observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, more, s_tile, P, w0, first, nw - first, lane);
-            }
+            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
             STAMP(5);
         } else
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
@@ -1230,13 +1212,11 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     q.wpw = kW;
     q.wpp = 0;
     q.whole = 1;
-    q.split = (kW >= 2 && ((kW / 2) * 2 * kC * 26) % 16 == 0) ? p.split : 0u;
     q.patch = 1;
     q.share = 0;
     q.steady = 0;
     q.tail_even = 1;
     q.private_consts = 1;
-    q.prio_mode = 0;
     q.terr_entries = kW * 2 * kC;
     q.off_pl = f.off_pl;
     q.off_x = f.off_x;
@@ -1862,7 +1842,6 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         memcpy(a.values_w, consts + kConstValues, 16);
         memcpy(&a.pots_w, consts + kConstPots, 4);
         a.tail_even = (a.P % 2 == 0) ? 1u : 0u;
-        a.prio_mode = (uint32_t)mrl::debug_get("overcooked.prio", 0);
         {
             // Multi-pass stream-out: write-through (sc1) stores stream the slab out while the waves still work, which pays
             // as long as the slab fits the 256 MiB Infinity Cache; larger slabs go out as plain stores through the L2
@@ -1908,7 +1887,6 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
             // with a background image the slab must start on a 16-byte boundary in every group
             a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave && wpw * a.block_bytes < 65536u) ? 1u : 0u;
-            a.split = (a.patch && wpw >= 2 && ((wpw / 2) * a.block_bytes) % 16u == 0 && mrl::debug_get("overcooked.split", 0)) ? 1u : 0u;
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 // with a.patch the tile is zeroed in whole 256-byte pieces (tile_zero_addtid)
@@ -1962,7 +1940,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_) {
                 const FixedLayout f = fixed_layout(C_, wpw_);
                 return a.P == 2 && !sim->generic && a.C == C_ && a.W == width_ && a.num_pots == pots_ && a.wpw == wpw_ && a.whole &&
-                       a.patch && !a.share && a.private_consts && a.prio_mode == 0 && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
+                       a.patch && !a.share && a.private_consts && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
                        a.off_cur == f.off_cur && a.off_flags == f.off_flags && a.off_terr == f.off_terr && a.off_list == f.off_list &&
                        a.off_tile == f.off_tile && a.lds_wave_stride == f.stride && !mrl::debug_get("overcooked.no_fixed", 0);
             };
