@@ -68,6 +68,11 @@ struct SimpleParams {
     int64_t horizon;
     const uint32_t *consts;
     const uint16_t *terr_pos;  // [rows]: offset of a row's terrain one-hot byte inside a world's block, 0xFFFF = none
+    // flat: every group's slab starts on a 16-byte boundary and its rows fit kGroupTerrPerLane x 64, so the static
+    // part of the tile is built like overcooked.hip's: ds_write_addtid zero fill + one table of tile offsets per GROUP
+    uint32_t flat;
+    const uint16_t *terr_off;  // [wpw * rows]: tile offset of a group row's terrain byte, 0 = none
+    uint32_t terr_entries;
     uint32_t *cell_obj;
     uint2 *players;
     int2 *clock;  // {timestep, num_dishes_out}
@@ -258,6 +263,7 @@ __device__ __forceinline__ void lds_store_tail10_bytes(uint8_t *ptr, const Tail1
 }
 
 constexpr int kTerrPosPerLane = 4;  // rows of one world <= 2 * 100
+constexpr int kGroupTerrPerLane = 7;  // rows of one GROUP in the flat mode (the standard layouts need 320..400)
 
 template <bool kInit, int kP>
 __device__ __forceinline__ void step_body(const SimpleParams &p)
@@ -295,6 +301,24 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
     uint32_t posori = 0, held = kItemNone, act = A_STAY;
     int2 clock = make_int2(0, 0);
     uint32_t tpos[kTerrPosPerLane];
+    uint32_t goff[kGroupTerrPerLane];
+    auto static_request = [&]() {
+        if (p.flat) {
+            const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.terr_off), 0, (int)(p.terr_entries * 2u), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < kGroupTerrPerLane; k++)
+                goff[k] = (uint32_t)k * kWave < p.terr_entries ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(tab, (int)((lane + (uint32_t)k * kWave) * 2u), 0, 0) : 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
+        }
+    };
+    auto static_zero = [&]() {
+        if (p.flat)
+            tile_zero_addtid(s_tile, nw * p.block_bytes);
+        else
+            for (uint32_t k = lane; k < (nw * p.block_bytes + 31u) >> 4; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+    };
     // ---------------- load ----------------
     if (!kInit) {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
@@ -315,11 +339,10 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         else
             a_raw = (uint32_t)p.actions[(size_t)q * N + world];
         clock = p.clock[world];
-#pragma unroll
-        for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
+        static_request();
         // while the loads are in flight: empty cell -> player map, zeroed tile
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        for (uint32_t k = lane; k < (nw * p.block_bytes + 31u) >> 4; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        static_zero();
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -331,21 +354,27 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         act = (active && a_raw <= A_INTERACT) ? a_raw : (uint32_t)A_STAY;  // outside the enum = outside the contract
         if ((p.sample || p.actions64) && active) p.action_out[(size_t)q * N + world] = (int32_t)(p.sample ? act : a_raw);
     } else {
-#pragma unroll
-        for (int k = 0; k < kTerrPosPerLane; k++) tpos[k] = p.terr_pos[min(lane + (uint32_t)k * kWave, p.rows - 1u)];
+        static_request();
         for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
-        for (uint32_t k = lane; k < (nw * p.block_bytes + 31u) >> 4; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        static_zero();
     }
     // the group's slab in HBM and its image in the tile are equally misaligned, so 16-byte chunks line up
     uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
     uint8_t *tile = s_tile + mis;
     // static part of the tile: the terrain one-hot byte of every row of a non-AIR, non-tomato-source cell
+    if (p.flat) {
+        const uint32_t limit = nw * p.block_bytes;  // a ragged last group holds fewer worlds
 #pragma unroll
-    for (int k = 0; k < kTerrPosPerLane; k++) {
-        const uint32_t i = lane + (uint32_t)k * kWave;
-        if (i < p.rows && tpos[k] != 0xFFFFu)
-            for (uint32_t l = 0; l < nw; l++) tile[__umul24(l, p.block_bytes) + tpos[k]] = 1;
+        for (int k = 0; k < kGroupTerrPerLane; k++)
+            if ((uint32_t)k * kWave < p.terr_entries && goff[k] != 0u && goff[k] < limit) tile[goff[k]] = 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kTerrPosPerLane; k++) {
+            const uint32_t i = lane + (uint32_t)k * kWave;
+            if (i < p.rows && tpos[k] != 0xFFFFu)
+                for (uint32_t l = 0; l < nw; l++) tile[__umul24(l, p.block_bytes) + tpos[k]] = 1;
+        }
     }
     if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
     __syncthreads();
@@ -485,7 +514,9 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const Simp
     q.off_cur = q.off_pl + up16c(kW * 2 * 8);
     q.off_list = q.off_cur + up16c(kW * kC);
     q.off_tile = q.off_list + up16c(kW * kC * 2 > 128 ? kW * kC * 2 : 128);
-    q.lds_wave_stride = q.off_tile + up16c(kW * 2 * kC * 20) + 48u;
+    q.flat = 1;  // (kW * 2 * kC * 20) % 16 == 0 for the four sizes below
+    q.terr_entries = kW * 2 * kC;
+    q.lds_wave_stride = q.off_tile + ((kW * 2 * kC * 20 + 255u) & ~255u) + 48u;
     step_body<false, 2>(q);
 }
 
@@ -724,10 +755,12 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.off_cur = a.off_pl + up16(wpw * a.P * 8);
         a.off_list = a.off_cur + up16(wpw * a.C);
         a.off_tile = a.off_list + up16(std::max(wpw * a.C * 2u, 128u));
-        a.lds_wave_stride = a.off_tile + up16(wpw * a.block_bytes) + 48u;
+        a.flat = ((wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kGroupTerrPerLane * kWave) ? 1u : 0u;
+        a.terr_entries = wpw * a.rows;
+        a.lds_wave_stride = a.off_tile + (a.flat ? ((wpw * a.block_bytes + 255u) & ~255u) : up16(wpw * a.block_bytes)) + 48u;
         sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
 #define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                                          \
-    if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ &&                       \
+    if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ && a.flat &&             \
         !mrl::debug_get("overcooked.no_fixed", 0)) {                                                                                 \
         sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 0>;                                             \
         sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 1>;                                             \
@@ -763,6 +796,13 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
             uint16_t *d_pos = sim->arena.alloc<uint16_t>(a.rows, false);
             MRL_HIP(hipMemcpy(d_pos, pos.data(), a.rows * sizeof(uint16_t), hipMemcpyHostToDevice));
             a.terr_pos = d_pos;
+            std::vector<uint16_t> off(a.terr_entries, 0);
+            for (uint32_t l = 0; l < a.wpw; l++)
+                for (uint32_t r = 0; r < a.rows; r++)
+                    if (pos[r] != 0xFFFFu) off[l * a.rows + r] = (uint16_t)(l * a.block_bytes + pos[r]);
+            uint16_t *d_off = sim->arena.alloc<uint16_t>(a.terr_entries, false);
+            MRL_HIP(hipMemcpy(d_off, off.data(), a.terr_entries * sizeof(uint16_t), hipMemcpyHostToDevice));
+            a.terr_off = d_off;
         }
         a.cell_obj = sim->arena.alloc<uint32_t>((size_t)N * C);
         a.players = sim->arena.alloc<uint2>((size_t)N * P);
