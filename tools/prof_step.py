@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--game", default="overcooked", choices=["overcooked", "hanabi", "cartpole"])
+    ap.add_argument("--game", default="overcooked", choices=["overcooked", "hanabi", "cartpole", "balance", "simplecooked"])
     ap.add_argument("--layout", default="cramped_room")
     ap.add_argument("--worlds", type=int, default=32768)
     ap.add_argument("--steps", type=int, default=200)
@@ -27,6 +27,19 @@ def main():
         params = layouts.get_base_layout_params(args.layout, 400, max_num_players=args.players)
         sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
         pool = [torch.randint(0, 6, (params["num_players"], n, 1), dtype=torch.int32, device="cuda") for _ in range(16)]
+        for i in range(args.steps):
+            sim.step_with_actions(pool[i % 16])
+    elif args.game == "balance":
+        from madrona_rl_envs_playground_amd.simulators import BalanceBeamSimulator
+        sim = BalanceBeamSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
+        pool = [torch.randint(0, 4, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(16)]
+        for i in range(args.steps):
+            sim.step_with_actions(pool[i % 16])
+    elif args.game == "simplecooked":
+        from madrona_rl_envs_playground_amd.simulators import SimplecookedSimulator
+        params = layouts.get_simplecooked_layout_params("simple", 400)
+        sim = SimplecookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+        pool = [torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(16)]
         for i in range(args.steps):
             sim.step_with_actions(pool[i % 16])
     elif args.game == "cartpole":
