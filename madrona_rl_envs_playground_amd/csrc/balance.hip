@@ -100,32 +100,23 @@ __device__ __forceinline__ void shift_history(Row &r, int32_t own, int32_t partn
     r.x[2 * kTime] = time;
 }
 
-__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint32_t &block_total)
-{
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long votes = __ballot(flag);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(votes);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < kBlock / 64; w++) {
-        const uint32_t c = s_wave[w];
-        before += w < wave ? c : 0;
-        total += c;
-    }
-    block_total = total;
-    return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
-}
-
 // workgroup b owns worlds [b*chunk, (b+1)*chunk), chunk a multiple of kBlock
 __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
                                                            int32_t *__restrict__ obs, float *__restrict__ reward,
                                                            int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
+                                                           unsigned long long *__restrict__ finished_mask,
                                                            int32_t *action_out, uint64_t sample_seed, uint32_t sample_step)
 {
+    // Besides the int32 done flags of the DONE tensor every wave stores the ballot of its 64 flags as one word of
+    // finished_mask (world w = bit w % 64 of word w / 64; chunk and kBlock are multiples of 64): the reset launch reads
+    // those words -- 128 bytes per 1024 worlds -- instead of walking the flags round by round.
     __shared__ uint32_t s_wave[kBlock / 64];
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
-    uint32_t finished = 0;
-    for (uint32_t w = first + threadIdx.x; w < last; w += kBlock) {
+    uint32_t finished = 0;  // wave-uniform
+    for (uint32_t w0 = first; w0 < last; w0 += kBlock) {  // uniform trip count
+        const uint32_t w = w0 + threadIdx.x;
+        bool over = false;
+        if (w < last) {
         Row r0 = load_row(obs, n, 0, w), r1 = load_row(obs, n, 1, w);
         int32_t a0, a1;
         if (action_out) {  // uniform over the four moves, drawn here (include/mrl_envs.h: mrl_rollout_random)
@@ -144,7 +135,6 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t 
         // checkDone (sim.cpp:114-151): double arithmetic, rounded to float once
         const int32_t gap = loc0 > loc1 ? loc0 - loc1 : loc1 - loc0;
         float rew = (float)(loc0 == loc1 ? 1.0 : -gap * 0.2);
-        bool over = false;
         if (loc0 < 0 || loc0 >= kSpaces || loc1 < 0 || loc1 >= kSpaces) {
             over = true;
             rew = (float)(-kSpaces * (time + 1) * 0.2);
@@ -157,9 +147,11 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t 
         reward[w] = rew;
         reward[(size_t)n + w] = rew;
         done[w] = over ? 1 : 0;
-        finished += over ? 1u : 0u;
+        }
+        const unsigned long long votes = __ballot(over);
+        if ((threadIdx.x & 63u) == 0 && w < last) finished_mask[w >> 6] = votes;
+        finished += (uint32_t)__popcll(votes);
     }
-    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -170,14 +162,18 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t 
 }
 
 // kAll: (re)initialise every world as episode world_offset + world (construction / mrl_reseed_shard)
+constexpr uint32_t kTripWords = 64;  // mask words (64 worlds each) the reset launch compacts per trip
 template <bool kAll>
-__global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t chunk, const int32_t *__restrict__ done,
+__global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t chunk, const unsigned long long *__restrict__ finished_mask,
                                                             int32_t *__restrict__ obs, const uint32_t *__restrict__ block_counts,
                                                             const uint32_t *__restrict__ episode_base, uint32_t world_offset,
                                                             uint32_t *__restrict__ next_counter, uint32_t *__restrict__ reset_count)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
+    __shared__ unsigned long long s_word[kTripWords];
+    __shared__ uint32_t s_before[kTripWords];
+    __shared__ uint32_t s_total;
+    __shared__ uint16_t s_list[kTripWords * 64];
     const bool last_block = blockIdx.x == gridDim.x - 1;
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
     if (kAll) {
@@ -189,23 +185,46 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t
         }
         return;
     }
+    const uint32_t words = (last - first + 63u) >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the first trip's mask words are requested before the prefix is summed
+    unsigned long long word = threadIdx.x < min(words, kTripWords) ? finished_mask[(first >> 6) + threadIdx.x] : 0ull;
     if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     uint32_t grand_total = 0;
     uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
     const uint32_t base = *episode_base;
-    for (uint32_t w0 = first; w0 < last; w0 += kBlock) {  // uniform trip count
-        const uint32_t w = w0 + threadIdx.x;
-        const bool over = w < last && done[w] != 0;
-        uint32_t total;
-        const uint32_t rank = block_rank(over, s_wave, total);
-        if (over) {
+    // finished worlds of a trip are compacted into s_list in ascending world order (entry e is the e-th finished
+    // world: episode base + running + e), then re-seeded one per thread on dense lanes
+    for (uint32_t w0 = 0; w0 < words; w0 += kTripWords) {  // uniform trip count
+        const uint32_t here = min(words - w0, kTripWords);
+        if (wave == 0) {
+            if (w0 > 0) word = lane < here ? finished_mask[(first >> 6) + w0 + lane] : 0ull;
+            const uint32_t c = (uint32_t)__popcll(word);
+            uint32_t x = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off, 64);
+                x += lane >= (uint32_t)off ? y : 0u;
+            }
+            s_word[lane] = word;
+            s_before[lane] = x - c;
+            if (lane == 63) s_total = x;
+        }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t k = wave; k < here; k += kBlock / 64) {  // one wave per word, lane = bit
+            const unsigned long long m = s_word[k];
+            if ((m >> lane) & 1ull) s_list[s_before[k] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((k << 6) + lane);
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < total; e += kBlock) {
+            const uint32_t w = first + (w0 << 6) + s_list[e];
             Row r0, r1;
-            fresh_rows(base + running + rank, r0, r1);
+            fresh_rows(base + running + e, r0, r1);
             store_row(obs, n, 0, w, r0);
             store_row(obs, n, 1, w, r1);
         }
         running += total;
-        __syncthreads();  // s_wave is reused by the next round
+        __syncthreads();  // s_word / s_before / s_list are rewritten by the next trip
     }
     if (last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
@@ -230,18 +249,19 @@ struct BalanceSim final : mrl_sim {
     int32_t *action = nullptr, *obs = nullptr, *done = nullptr, *world_id = nullptr, *agent_id = nullptr, *active = nullptr, *mask = nullptr;
     float *reward = nullptr;
     uint32_t *block_counts = nullptr, *counter = nullptr, *reset_count = nullptr;
+    unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
 
     void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
     {
         hipLaunchKernelGGL(mrl_balance_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, actions ? actions : action, obs, reward,
-                           done, block_counts, action_out, seed, sample_step);
+                           done, block_counts, finished_mask, action_out, seed, sample_step);
         MRL_HIP(hipGetLastError());
     }
     void phase1(const int32_t *actions, hipStream_t stream) override { launch_step(actions, nullptr, 0, 0, stream); }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
         const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
-        hipLaunchKernelGGL((mrl_balance_reset<false>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, obs, block_counts, base,
+        hipLaunchKernelGGL((mrl_balance_reset<false>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, base,
                            0u, counter + (parity ^ 1u), reset_count);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -262,7 +282,7 @@ struct BalanceSim final : mrl_sim {
     {
         const uint32_t *none = nullptr;
         uint32_t *no_out = nullptr;
-        hipLaunchKernelGGL((mrl_balance_reset<true>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, done, obs, block_counts, none,
+        hipLaunchKernelGGL((mrl_balance_reset<true>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, none,
                            world_offset, no_out, no_out);
         MRL_HIP(hipGetLastError());
         MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
@@ -326,6 +346,7 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
         sim->active = sim->arena.alloc<int32_t>(2 * N, false);
         sim->mask = sim->arena.alloc<int32_t>(2 * N * 4, false);
         sim->block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        sim->finished_mask = sim->arena.alloc<unsigned long long>(((size_t)sim->grid * sim->chunk + 63) / 64);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         hipLaunchKernelGGL(fill_balance_ids, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, 0, sim->world_id, sim->agent_id, sim->active,
