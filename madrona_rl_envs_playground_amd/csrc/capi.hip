@@ -21,6 +21,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size
     "overcooked.store_policy",  // multi-pass stream-out stores: 0 by slab size (default), 1 sc1 write-through, 2 plain, 3 nt
+    "overcooked.wide_rollout",  // 1: the multi-step launches keep the single step's group size (default: twice as wide where it fits)
     "overcooked.groups",     // groups of worlds a wave steps one after the other in the single step of the standard layouts: 0 by batch size, 1, 2
     "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do
     "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition

@@ -1606,6 +1606,11 @@ struct OvercookedSim final : mrl_sim {
     uint32_t groups_grid = 0;
     const char *groups_name = nullptr;
     void (*fixed_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
+    // the multi-step launches with twice as many worlds per wave (half as many waves: the state lives in LDS / registers for
+    // the whole launch, so there is no load phase to hide behind other waves and fewer, fatter waves issue fewer instructions)
+    void (*wide_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
+    StepParams wide_params{};
+    uint32_t wide_grid = 0, wide_lds = 0;
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
@@ -1644,7 +1649,10 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (fixed_rollout)
+            if (wide_rollout)
+                hipLaunchKernelGGL(wide_rollout, dim3(wide_grid), dim3(kWavesPerBlock * kWave), wide_lds, stream, wide_params, num_steps,
+                                   seed, first_step, action, (const int32_t *)nullptr);
+            else if (fixed_rollout)
                 hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, seed,
                                    first_step, action, (const int32_t *)nullptr);
             else if (params.P == 2 && !generic)
@@ -1668,7 +1676,10 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
-            if (fixed_rollout)
+            if (wide_rollout)
+                hipLaunchKernelGGL(wide_rollout, dim3(wide_grid), dim3(kWavesPerBlock * kWave), wide_lds, stream, wide_params, num_steps,
+                                   0ull, 0u, action, actions);
+            else if (fixed_rollout)
                 hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, 0ull, 0u,
                                    action, actions);
             else if (params.P == 2 && !generic)
@@ -2006,6 +2017,41 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             uint16_t *d_off = sim->arena.alloc<uint16_t>(a.terr_entries, false);
             MRL_HIP(hipMemcpy(d_off, off.data(), a.terr_entries * sizeof(uint16_t), hipMemcpyHostToDevice));
             a.terr_off = d_off;
+        }
+        // Multi-step launches of the standard layouts: groups twice as wide where the table of terrain offsets and the
+        // LDS of two workgroups per CU allow (measured in DESIGN.md 4.1; mrl_debug_set overcooked.wide_rollout 1 = never)
+        if (sim->fixed_rollout && mrl::debug_get("overcooked.wide_rollout", 0) != 1) {
+            const uint32_t rw = 2u * a.wpw;
+            uint32_t stride = 0;
+#define MRL_WIDE(C_, W2_, WIDTH_, POTS_)                                                                             \
+    if (!sim->wide_rollout && a.C == C_ && rw == W2_ && a.W == WIDTH_ && a.num_pots == POTS_) {                      \
+        sim->wide_rollout = &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_>;                                  \
+        stride = fixed_layout(C_, W2_).stride;                                                                      \
+    }
+            MRL_WIDE(20, 16, 5, 1)  // cramped_room
+            MRL_WIDE(25, 8, 5, 2)   // coordination_ring, forced_coordination
+            MRL_WIDE(40, 8, 8, 2)   // counter_circuit
+#undef MRL_WIDE
+            const uint32_t wide_waves = (N + rw - 1) / rw;
+            if (sim->wide_rollout && (rw * a.rows > (uint32_t)kTerrPosPerLane * kWave || wide_waves < 2048u)) sim->wide_rollout = nullptr;
+            if (sim->wide_rollout) {
+                sim->wide_params = a;
+                sim->wide_lds = kConstBytes + kWavesPerBlock * stride;
+                sim->wide_grid = (((wide_waves + kWavesPerBlock - 1) / kWavesPerBlock) + 7u) & ~7u;
+                std::vector<uint16_t> off((size_t)rw * a.rows, 0);
+                for (uint32_t l = 0; l < rw; l++)
+                    for (uint32_t v = 0; v < a.P; v++)
+                        for (uint32_t c = 0; c < a.C; c++) {
+                            const uint32_t t = consts[kConstTerrain + c];
+                            if (t != T_AIR) off[l * a.rows + v * a.C + c] = (uint16_t)(l * a.block_bytes + (v * a.C + c) * a.F + 5 * a.P + t - 1);
+                        }
+                uint16_t *d_off = sim->arena.alloc<uint16_t>(off.size(), false);
+                MRL_HIP(hipMemcpy(d_off, off.data(), off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                sim->wide_params.terr_off = d_off;
+                if (sim->wide_lds > 65536)
+                    MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sim->wide_rollout), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)sim->wide_lds));
+            }
         }
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
