@@ -492,13 +492,10 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
 // and LDS offsets fold -- the kernel is bound by instruction issue, not by bytes.  Launched only when
 // the simulator's parameters are exactly these; results are identical.
 constexpr uint32_t up16c(uint32_t v) { return (v + 15u) & ~15u; }
-// kSource: where the actions come from -- 0 the int32 array, 1 the caller's int64 tensor, 2 drawn in the kernel
-template <int kC, int kW, int kWidth, int kPots, int kSource = 0>
-__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const SimpleParams p)
+template <int kC, int kW, int kWidth, int kPots>
+__device__ __forceinline__ SimpleParams fixed_simple_params(const SimpleParams &p)
 {
     SimpleParams q = p;
-    if (kSource != 1) q.actions64 = nullptr;
-    if (kSource != 2) q.sample = 0;
     q.P = 2;
     q.C = kC;
     q.W = kWidth;
@@ -517,7 +514,205 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const Simp
     q.flat = 1;  // (kW * 2 * kC * 20) % 16 == 0 for the four sizes below
     q.terr_entries = kW * 2 * kC;
     q.lds_wave_stride = q.off_tile + ((kW * 2 * kC * 20 + 255u) & ~255u) + 48u;
+    return q;
+}
+
+// kSource: where the actions come from -- 0 the int32 array, 1 the caller's int64 tensor, 2 drawn in the kernel
+template <int kC, int kW, int kWidth, int kPots, int kSource = 0>
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const SimpleParams p)
+{
+    SimpleParams q = fixed_simple_params<kC, kW, kWidth, kPots>(p);
+    if (kSource != 1) q.actions64 = nullptr;
+    if (kSource != 2) q.sample = 0;
     step_body<false, 2>(q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// num_steps steps in ONE launch (two players, flat tile): mrl_rollout_random draws the uniform random policy in the
+// kernel (the same stream as the per-step path: policy_hash(seed, first_step + k, world, player) scaled to six
+// actions), mrl_step_sequence reads an open-loop (num_steps, P, N) action array.  Like overcooked.hip's multi-step
+// launches: cell objects in LDS, players and clocks in registers, the observation tile zeroed and given its terrain
+// bytes once -- a step patches what is dynamic now, streams the tile out and puts the patched rows back.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
+                                             const int32_t *action_seq)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t P = 2;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
+    const uint8_t *s_terrain = smem + kConstTerrain;
+    const uint8_t *s_pots = smem + kConstPots;
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
+    const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
+    uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(wbase + p.off_pl);
+    uint8_t *s_cur = wbase + p.off_cur;
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(wbase + p.off_list);
+    uint8_t *tile = wbase + p.off_tile;  // flat: every group's slab starts on a 16-byte boundary
+    const uint32_t C = p.C, N = p.num_worlds, F = p.F;
+    const uint32_t ncells = nw * C, nplayers = nw * P;
+    const uint32_t wl = lane >> 1, q = lane & 1u;
+    const bool active = lane < nplayers;
+    const uint32_t world = min(w0 + wl, N - 1u);
+
+    uint32_t posori = 0, held = kItemNone;
+    int32_t t = 0, dishes_out = 0;
+    {
+        const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
+        const int2 clock = p.clock[world];
+        const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.terr_off), 0, (int)(p.terr_entries * 2u), 0x00020000);
+        uint32_t goff[kGroupTerrPerLane];
+#pragma unroll
+        for (int k = 0; k < kGroupTerrPerLane; k++)
+            goff[k] = (uint32_t)k * kWave < p.terr_entries ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(tab, (int)((lane + (uint32_t)k * kWave) * 2u), 0, 0) : 0u;
+        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        tile_zero_addtid(tile, nw * p.block_bytes);
+        for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
+        const uint32_t limit = nw * p.block_bytes;
+#pragma unroll
+        for (int k = 0; k < kGroupTerrPerLane; k++)
+            if ((uint32_t)k * kWave < p.terr_entries && goff[k] != 0u && goff[k] < limit) tile[goff[k]] = 1;
+        if (active) {
+            posori = pl_reg.x & 0xFFFFu;
+            held = pl_reg.y;
+        }
+        t = clock.x;
+        dishes_out = clock.y;
+    }
+    if (tid < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid] = const_word;
+    __syncthreads();
+    if (nw == 0) return;
+    if (active) s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+    wave_lds_sync();
+
+    const uint32_t plane = __umul24(C, F), shift = 5 * P;
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    int32_t ahead = 0;  // mrl_step_sequence: the next step's action is requested before this step's encode
+    if (action_seq) ahead = action_seq[(size_t)(active ? q : 0u) * N + world];
+    for (uint32_t k = 0; k < num_steps; k++) {
+        uint32_t a;
+        if (action_seq) {
+            a = (uint32_t)ahead;
+            if (k + 1 < num_steps) ahead = action_seq[((size_t)(k + 1) * P + (active ? q : 0u)) * N + world];
+        } else {
+            a = mrl::scale(mrl::policy_hash(seed, first_step + k, world, q), 6u);
+        }
+        if (!action_seq && active && k + 1 == num_steps) p.action_out[(size_t)q * N + world] = (int32_t)a;  // the ACTION tensor shows the last draw
+        a = (active && a <= A_INTERACT) ? a : (uint32_t)A_STAY;
+        const uint32_t old_cell = wl * C + (posori & 0xFFu);
+        int32_t reward_world = 0;
+        transition<2>(p, s_terrain, s_pots, s_obj, active, wl, q, a, posori, held, dishes_out, reward_world);
+        tick_pots(p, s_pots, s_obj, nw, lane);
+        t += 1;
+        const bool reset_now = (int64_t)t >= p.horizon;
+        if (__ballot(active && reset_now) != 0ull) {
+            if (reset_now) {
+                t = 0;
+                dishes_out = 0;
+                posori = ((p.starts >> (8u * q)) & 0xFFu) | (A_NORTH << 8);
+                held = kItemNone;
+            }
+            if (active && q == 0) s_list[wl] = reset_now ? 1 : 0;
+            wave_lds_sync();
+            for (uint32_t i = lane; i < ncells; i += kWave)
+                if (s_list[__umulhi(i, p.inv_c)] != 0) s_obj[i] = kItemNone;
+            wave_lds_sync();
+        }
+        // every lane clears its old cell before any lane marks its new one (two DS instructions, in order)
+        if (active) s_cur[old_cell] = 0xFF;
+        wave_lds_sync();
+        if (active) {
+            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+        }
+        wave_lds_sync();
+        uint32_t ndyn = 0;
+        for (uint32_t i0 = 0; i0 < ncells; i0 += kWave) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < ncells;
+            const uint32_t o = s_obj[valid ? i : 0u];
+            const uint32_t who = s_cur[valid ? i : 0u];
+            const bool dyn = valid && (((o & 0xFFu) != O_NONE) | (who != 0xFFu));
+            const unsigned long long m = __ballot(dyn);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (dyn) s_list[ndyn + before] = (uint16_t)i;
+            ndyn += (uint32_t)__popcll(m);
+        }
+        wave_lds_sync();
+        const uint32_t nent = ndyn * P;
+        auto rows = [&](bool restore) {
+            for (uint32_t j = lane; j < nent; j += kWave) {
+                const uint32_t kk = j >> 1, v = j & 1u;
+                const uint32_t i = s_list[kk];
+                const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
+                const uint32_t who = s_cur[i];
+                const bool occupied = who != 0xFF;
+                const uint32_t pidx = (__umul24(l, P) + (occupied ? who : 0u)) * 2;
+                const uint32_t w_ori = (s_pl[pidx] >> 8) & 0xFF;
+                const uint32_t h = occupied ? s_pl[pidx + 1] : kItemNone;
+                const Tail10 t10 = restore ? cell_tail(s_terrain[c], kItemNone, kItemNone) : cell_tail(s_terrain[c], s_obj[i], h);
+                uint8_t *row = tile + __umul24(l, p.block_bytes) + __umul24(v, plane) + __umul24(c, F);
+                lds_store_tail10_p2(row + shift, t10);
+                if (occupied) {
+                    const uint32_t rel = who == v ? 0u : (who < v ? who + 1u : who);
+                    row[rel] = restore ? 0 : 1;
+                    row[P + 4 * rel + w_ori] = restore ? 0 : 1;
+                }
+            }
+        };
+        rows(false);
+        wave_lds_sync();
+        {
+            const uint32_t nbytes = nw * p.block_bytes;
+            const uint32_t body = nbytes >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+            const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs, 0, (int)(body << 4), 0x00020000);
+            for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+                const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+                const uint32_t last = body - 1u;
+                const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
+                stream_store_rsrc(out, ka << 4, va);
+                stream_store_rsrc(out, kb << 4, vb);
+                stream_store_rsrc(out, kc << 4, vc);
+                stream_store_rsrc(out, kd << 4, vd);
+            }
+            const uint32_t done_bytes = body << 4;
+            if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
+        }
+        wave_lds_sync();
+        rows(true);  // the patched rows go back to their static content
+        if (active) {
+            p.reward[(size_t)q * N + world] = reward_world;
+            if (q == 0) p.done[world] = (int32_t)reset_now;
+        }
+        wave_lds_sync();
+    }
+    uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+    for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
+    if (active) {
+        p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+        if (q == 0) p.clock[world] = make_int2(t, dishes_out);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout(const SimpleParams p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
+                                                                   const int32_t *action_seq)
+{
+    rollout_body(p, num_steps, seed, first_step, action_seq);
+}
+
+template <int kC, int kW, int kWidth, int kPots>
+__global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout_fixed(const SimpleParams p, uint32_t num_steps, uint64_t seed,
+                                                                         uint32_t first_step, const int32_t *action_seq)
+{
+    rollout_body(fixed_simple_params<kC, kW, kWidth, kPots>(p), num_steps, seed, first_step, action_seq);
 }
 
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
@@ -539,6 +734,7 @@ struct SimplecookedSim final : mrl_sim {
     SimpleParams params{};
     uint32_t H = 0, grid = 0, lds_bytes = 0;
     void (*fixed_kernel[3])(const SimpleParams) = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
+    void (*fixed_rollout)(const SimpleParams, uint32_t, uint64_t, uint32_t, const int32_t *) = nullptr;
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
@@ -577,9 +773,32 @@ struct SimplecookedSim final : mrl_sim {
         return true;
     }
 
-    // uniform random policy on the device: the draw happens in the step kernel, one launch per step
+    // all steps of a call in one launch (two players, flat tile; see rollout_body)
+    bool launch_rollout(uint32_t num_steps, uint64_t seed, uint32_t first_step, const int32_t *action_seq, hipStream_t stream)
+    {
+        if (params.P != 2 || !params.flat) return false;
+        SimpleParams a = params;
+        a.action_out = action;
+        if (fixed_rollout)
+            hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
+        else
+            hipLaunchKernelGGL(mrl_simplecooked_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
+        MRL_HIP(hipGetLastError());
+        return true;
+    }
+
+    void step_sequence(const int32_t *actions, uint32_t num_steps, hipStream_t stream) override
+    {
+        if (num_steps == 0) return;
+        if (!launch_rollout(num_steps, 0, 0, actions, stream)) mrl_sim::step_sequence(actions, num_steps, stream);
+    }
+
+    // uniform random policy on the device: one launch for all steps where the layout allows, else the draw happens in the
+    // step kernel, one launch per step
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
+        if (num_steps == 0) return;
+        if (launch_rollout(num_steps, seed, first_step, nullptr, stream)) return;
         SimpleParams a = params;
         a.actions = action;
         a.sample = 1;
@@ -765,6 +984,7 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 0>;                                             \
         sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 1>;                                             \
         sim->fixed_kernel[2] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 2>;                                             \
+        sim->fixed_rollout = &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                               \
         sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", 0>";                             \
     }
         // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave

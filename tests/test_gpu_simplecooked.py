@@ -117,9 +117,13 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
             a = torch.randint(0, 6, (P, n, 1), dtype=torch.int64, device="cuda", generator=gen)
             fixed.step_with_actions_i64(a)
             generic.step_with_actions_i64(a)
+        elif t % 6 == 2:
+            fixed.rollout_random(5, seed=9, first_step=5 * t)   # all five steps in one launch, tile reused
+            generic.rollout_random(5, seed=9, first_step=5 * t)
         else:
-            fixed.rollout_random(1, seed=9, first_step=t)
-            generic.rollout_random(1, seed=9, first_step=t)
+            seq = torch.randint(0, 6, (4, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            fixed.step_sequence(seq)
+            generic.step_sequence(seq)
         for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "action_tensor", "state_objects_tensor",
                     "state_players_tensor", "state_timestep_tensor"):
             assert torch.equal(getattr(fixed, get)().to_torch(), getattr(generic, get)().to_torch()), f"{get}, step {t}"
@@ -128,13 +132,14 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
 
 
 def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
-    """mrl_rollout_random draws the documented stream in the step kernel; mrl_step_sequence == single steps."""
+    """mrl_rollout_random draws the documented stream (all steps of a call in one launch, state and tile resident);
+    mrl_step_sequence runs an action array the same way; both equal the oracle and one launch per step."""
     from madrona_rl_envs_playground_amd.simulators import random_action
     params = layouts.get_simplecooked_layout_params("random1", 23)
     n, P = 2051, 2
     seed = 0xABCDEF0123
     orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
-    sim, twin = make_sim(params, n), make_sim(params, n)
+    sim, twin, single = make_sim(params, n), make_sim(params, n), make_sim(params, n)  # one launch / one launch / one launch per step
     o = sim.observation_world_major_tensor().to_torch().view(orc.obs.shape)
     world, player = np.meshgrid(np.arange(n), np.arange(P))
     k = 100
@@ -146,6 +151,8 @@ def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
             orc.step(acts)
             seq.append(torch.from_numpy(acts).view(P, n, 1))
         twin.step_sequence(torch.stack(seq).cuda().contiguous())
+        for a in seq:
+            single.step_with_actions(a.cuda().contiguous())
         k += chunk
         assert np.array_equal(sim.action_tensor().to_torch().cpu().numpy()[..., 0], acts)
         assert np.array_equal(o.cpu().numpy().astype(np.uint8), orc.obs), f"obs differ after step {k}"
@@ -154,8 +161,10 @@ def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
         for name in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_players_tensor", "state_objects_tensor",
                      "state_timestep_tensor", "dishes_out_tensor"):
             assert torch.equal(getattr(sim, name)().to_torch(), getattr(twin, name)().to_torch()), name
+            assert torch.equal(getattr(sim, name)().to_torch(), getattr(single, name)().to_torch()), name
     sim.close()
     twin.close()
+    single.close()
 
 
 def test_env_wrapper_and_reference_views(hip_lib):

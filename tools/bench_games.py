@@ -94,6 +94,11 @@ def main():
     gbps = sim.bytes_per_world_step * n / dev / 1e9
     out["simplecooked"] = {"layout": "simple", "worlds": n, "us_per_step": dev * 1e6, "steps_per_s": n / dev, "bytes_per_world_step":
                            sim.bytes_per_world_step, "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0, "kernel": sim.kernel_name}
+    wall, dev = timed(lambda i: sim.rollout_random(500, seed=3, first_step=500 * i), 4)
+    roll_bytes = 2 * 20 * 20 + 8 + 4  # observations + rewards + done flag; state and actions stay on the chip
+    out["simplecooked"].update({"us_per_step_device_policy": dev / 500 * 1e6, "steps_per_s_device_policy": n * 500 / dev,
+                                "device_policy_bytes_per_world_step": roll_bytes,
+                                "algorithmic_GBps_device_policy": roll_bytes * n * 500 / dev / 1e9})
     sim.close()
     n = 1 << 20
     sim = BalanceBeamSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
