@@ -17,6 +17,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.wpw",        // worlds per wave (0 = chosen by the library)
     "overcooked.whole_max",  // largest single-pass observation tile, bytes
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
+    "overcooked.share_max_players",  // experiment: up to how many players the four waves of a workgroup share one world of a large layout
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size

@@ -1942,10 +1942,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         }
         // Few worlds of a large layout leave most of the GPU idle at one wave per world: the four waves of a
         // workgroup then share a world.  Measured on many_player_layout (15x17) at 1000 worlds, us per step
-        // shared / not: 2 players 9.4 / 10.3, 4 players 14.6 / 18.4, 8 players 36.8 / 32.6, 16 players 97 / 85,
-        // 30 players 564 / 521 -- with many players the redundant transition (serial in the player count, one
-        // active lane) costs more than the extra waves bring, so only up to four players.
-        a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= 4 && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
+        // shared / not: 2 players 9.4 / 10.3, 4 players 14.6 / 18.4; with round 1's transition (serial in the player
+        // count on one lane, redundant in every sibling wave) more players lost (8: 36.8 / 32.6, 30: 564 / 521), with
+        // the lane-per-player transition they no longer do (8: 30.7 / 30.8, 16: 82.7 / 86.7, 30: 253 / 260), so any count.
+        a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= (uint32_t)mrl::debug_get("overcooked.share_max_players", 64) && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
         {
             // a kernel specialised for this layout size, if there is one and the parameters are exactly what it assumes
             auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_) {
