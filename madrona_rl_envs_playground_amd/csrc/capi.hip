@@ -21,6 +21,8 @@ static const char *const kDebugKeys[] = {
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size
+    "overcooked.no_direct",  // 1: the single-pass encode looks for its dynamic cells (cell -> player map + ballot compaction) instead of
+                             // taking them from the player lanes and the holder-cell table
     "overcooked.store_policy",  // multi-pass stream-out stores: 0 by slab size (default), 1 sc1 write-through, 2 plain, 3 nt
     "overcooked.wide_rollout",  // 1: the multi-step launches keep the single step's group size (default: twice as wide where it fits)
     "overcooked.groups",     // groups of worlds a wave steps one after the other in the single step of the standard layouts: 0 by batch size, 1, 2

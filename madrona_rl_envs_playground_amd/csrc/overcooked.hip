@@ -87,6 +87,7 @@ struct StepParams {
     uint32_t times_w[4], values_w[4];  // the 16-entry recipe tables, 4 bytes per word (scalar registers)
     uint32_t pots_w;       // cells of the first four pots, one byte each
     uint32_t wpw;          // worlds per wave
+    uint32_t per_xcd;      // workgroups of the launch / 8 (set per launch: the XCD-aware block -> world mapping)
     uint32_t wpp;          // whole worlds per observation pass (0: a world spans several passes)
     uint32_t num_pots;
 #ifdef MRL_DIAG
@@ -106,6 +107,12 @@ struct StepParams {
     uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
     const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
     uint32_t terr_entries;     // wpw * rows
+    // p.direct (see patch_direct): the encode needs no search for what is dynamic.  Players only ever stand on AIR cells and
+    // objects only ever lie on counters / pots a player can face (HOLDER cells); the host checks the start cells and builds
+    // the table of a group's holder cells: entry [k * 64 + lane], lanes below wpw * P of round 0 left free for the players
+    uint32_t direct;
+    const uint32_t *hold_tab;  // device, [hold_entries]: tile offset of the cell's viewer-0 row | cell index in the group << 16 | 1 << 30 | is_pot << 31
+    uint32_t hold_entries;
     uint32_t off_pl, off_x, off_sum, off_cur, off_flags, off_list, off_tail, off_tile;  // byte offsets inside a wave's LDS region
     uint32_t lds_wave_stride;
     int64_t horizon;
@@ -407,7 +414,9 @@ __device__ __forceinline__ void transition_lanes(const StepParams &p, const uint
     const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held));
     uint32_t *cell = s_obj + (touches ? wl * C + tgt : 0u);
     constexpr uint32_t kRounds = kP == 2 ? 2u : 4u;  // at most four players face one cell
-#pragma unroll
+    // one copy of the interaction code for all rounds (rounds after the first are rare and the launch is sensitive to
+    // the size of its straight-line code: DESIGN.md 4.1)
+#pragma clang loop unroll(disable)
     for (uint32_t r = 0; r < kRounds; r++) {
         const bool todo = inter && rank == r;
         if (r > 0 && __ballot(todo) == 0ull) break;
@@ -596,6 +605,68 @@ __device__ __forceinline__ uint32_t find_dynamic(const StepParams &p, const uint
     return ndyn;
 }
 
+// p.direct: what is dynamic in a group is known without looking for it.  A player only ever stands on an AIR cell (moves go to AIR
+// cells, sim.cpp:363-379; the host checks the start cells) and an object only ever lies on a counter or in a pot that a player can
+// face (put / add are the only ways an object reaches a cell, sim.cpp:229-253,299-335) -- so a group's dynamic rows are the rows of
+// its players' cells, encoded by the PLAYER lanes straight from their registers (terrain AIR, no object, what the player holds), and
+// the rows of the HOLDER cells that hold something, one lane per holder cell from a table built on the host.  No cell -> player map,
+// no ballot compaction, no list: one LDS read (the holder's object) between the transition and the patch stores.
+constexpr int kHoldPerLane = 4;  // 256 table entries per group
+struct HoldTab {
+    uint32_t e[kHoldPerLane];
+};
+__device__ __forceinline__ void hold_request(const StepParams &p, uint32_t lane, HoldTab &h)
+{
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.hold_tab), 0, (int)(p.hold_entries * 4u), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < kHoldPerLane; k++) {
+        if ((uint32_t)k * kWave >= p.hold_entries) {  // wave-uniform
+            h.e[k] = 0;
+            continue;
+        }
+        h.e[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(tab, (int)((lane + (uint32_t)k * kWave) * 4u), 0, 0);
+    }
+}
+// kUndo: put the same rows back to their static content (after the stream-out of a tile that outlives the step)
+template <int kP, bool kUndo>
+__device__ __forceinline__ void patch_direct(const StepParams &p, const uint32_t *s_obj, const uint8_t *s_flags, const HoldTab &hold,
+                                             uint8_t *tile, uint32_t P, uint32_t nw, bool active, uint32_t wl, uint32_t q, uint32_t posori,
+                                             uint32_t held)
+{
+    const uint32_t C = p.C, F = p.F, shift = 5 * P, ncells = nw * C;
+    const uint32_t plane = __umul24(C, F);
+    const uint32_t ori = (posori >> 8) & 0xFFu;
+#pragma unroll
+    for (int k = 0; k < kHoldPerLane; k++) {
+        if (k > 0 && (uint32_t)k * kWave >= p.hold_entries) break;  // wave-uniform
+        const uint32_t e = hold.e[k];
+        const uint32_t i = (e >> 16) & 0x3FFFu;
+        const bool holder = ((e >> 30) & 1u) != 0u && i < ncells;
+        const uint32_t o = s_obj[holder ? i : 0u];
+        const bool player = k == 0 && active;
+        if (player || (holder && (o & 0xFFu) != O_NONE)) {
+            const uint32_t l = player ? wl : __umulhi(i, p.inv_c);
+            const uint32_t terr = player ? (uint32_t)T_AIR : ((e >> 31) ? (uint32_t)T_POT : (uint32_t)T_COUNTER);
+            const uint4 t = cell_tail(p, terr, (player || kUndo) ? (uint32_t)kItemNone : o, (player && !kUndo) ? held : (uint32_t)kItemNone, s_flags[l]);
+            uint8_t *row0 = tile + (player ? __umul24(l, p.block_bytes) + __umul24(posori & 0xFFu, F) : (e & 0xFFFFu));
+            auto viewer_row = [&](uint32_t v, uint8_t *row) {
+                lds_store_tail_even(row + shift, t);
+                if (player) {
+                    const uint32_t rel = q == v ? 0u : (q < v ? q + 1u : q);
+                    row[rel] = kUndo ? 0 : 1;
+                    row[P + 4 * rel + ori] = kUndo ? 0 : 1;
+                }
+            };
+            if constexpr (kP == 2) {
+                viewer_row(0, row0);
+                viewer_row(1, row0 + plane);
+            } else {
+                for (uint32_t v = 0; v < P; v++) viewer_row(v, row0 + __umul24(v, plane));
+            }
+        }
+    }
+}
+
 // kRestore (persistent rollouts, where the tile outlives the step): after the stream-out the patched rows are
 // put back to their static content, so the next step again only touches what is dynamic then; s_prev remembers
 // each world's urgency flag as the tile has it.
@@ -603,7 +674,8 @@ template <int kP, bool kRestore>
 __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags, uint8_t *s_prev,
                                               const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t l0,
-                                              uint32_t nl, uint32_t lane)
+                                              uint32_t nl, uint32_t lane, const HoldTab &hold, bool active, uint32_t wl, uint32_t q,
+                                              uint32_t posori, uint32_t held)
 {
     // worlds l0 .. l0 + nl - 1 of the group (the single step encodes a group in two halves so that the first
     // half's stores are on their way while the second is still being patched); `tile` is the whole group's
@@ -613,7 +685,8 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 #endif
     const uint32_t plane = __umul24(C, F);  // bytes of one viewer's rows
     // lane = dynamic cell; its 16-byte tail is worked out once and dropped into the rows of all P viewers
-    for (uint32_t j = lane; j < ndyn; j += kWave) {
+    if (p.direct) patch_direct<kP, false>(p, s_obj, s_flags, hold, tile, P, nl, active, wl, q, posori, held);
+    for (uint32_t j = lane; j < (p.direct ? 0u : ndyn); j += kWave) {
         const uint32_t i = s_list[j];
         const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
         const uint32_t terr = s_terrain[c];
@@ -683,7 +756,8 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = reinterpret_cast<const uint8_t *>(src)[done_bytes + lane];
     if constexpr (kRestore) {
         wave_lds_sync();
-        for (uint32_t j = lane; j < ndyn; j += kWave) {
+        if (p.direct) patch_direct<kP, true>(p, s_obj, s_flags, hold, tile, P, nl, active, wl, q, posori, held);
+        for (uint32_t j = lane; j < (p.direct ? 0u : ndyn); j += kWave) {
             const uint32_t i = s_list[j];
             const uint32_t l = __umulhi(i, p.inv_c), c = i - __umul24(l, C);
             const uint32_t who = s_cur[i];
@@ -816,6 +890,12 @@ __device__ __forceinline__ void step_body(const StepParams &p)
 
     STAMP(0);
     STAMP_REALTIME(13);
+#ifdef MRL_DIAG
+    // where the wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, for tools/hwid_map.py
+    if (p.stamps && lane == 0)
+        p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + wib) * 16 + 12] =
+            (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
     if (ABLATED(16)) return;  // diagnostic build: the empty launch
     // the constants and the group's state slab are fetched together: one HBM/L2 latency.  Small configurations
     // (p.private_consts) need only the terrain in LDS, one private copy per wave: no barrier, the waves never meet.
@@ -836,7 +916,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so
     // give each XCD one contiguous range of worlds (neighbouring groups share
     // cache lines of the state arrays and of the observation slab; keep them in one L2).
-    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t per_xcd = p.per_xcd;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t w0 = p.share ? logical_block : (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
@@ -864,6 +944,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     uint32_t posori = 0, held = kItemNone, act = A_STAY;
     int32_t t_loaded = 0;
     TerrPos tpos;
+    HoldTab hold{};
     // ---------------- load: HBM slab -> LDS (straight copies) ----------------
     // All global loads of the group are issued before the first one is consumed (explicitly
     // batched: a plain copy loop waits for each load before issuing the next, which measured
@@ -885,11 +966,13 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
         if (p.patch) terrain_request(p, lane, tpos);
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (!p.direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
             tile_zero_addtid(s_tile, nw * p.block_bytes);
         else if (p.whole)
             tile_zero(p, lane, s_tile, nw);
+        if (p.direct) hold_request(p, lane, hold);  // not among the preloaded arguments: asked for behind the fill
         STAMP(6);
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
@@ -907,11 +990,13 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         }
     } else {
         if (p.patch) terrain_request(p, lane, tpos);
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (!p.direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
             tile_zero_addtid(s_tile, nw * p.block_bytes);
         else if (p.whole)
             tile_zero(p, lane, s_tile, nw);
+        if (p.direct) hold_request(p, lane, hold);
     }
     if (p.patch) terrain_deliver(p, tpos, s_tile, nw);
     if (private_consts) {
@@ -957,8 +1042,10 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     STAMP(2);
     // what the encode reads: player records, cell -> player map, urgency channel (sim.cpp:79-83)
     if (active) {
-        reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
-        s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+        if (!p.direct) {
+            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+        }
         if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
     }
     wave_lds_sync();
@@ -970,6 +1057,18 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     auto store_state = [&]() {
         if (p.share && wib != 0) return;  // the siblings computed the same state
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+#ifdef MRL_STATE_SC1
+        for (uint32_t i = lane; i < ncells; i += kWave) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(g_obj + i), "v"(s_obj[i]) : "memory");
+        if (active) {
+            const uint32_t world = w0 + wl;
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p.players + (size_t)w0 * P + lane), "v"(make_uint2(posori, held)) : "memory");
+            asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p.reward + (size_t)q * N + world), "v"(reward_world) : "memory");
+            if (q == 0) {
+                asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p.timestep + world), "v"(t) : "memory");
+                asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p.done + world), "v"(kInit ? 0 : (int32_t)reset_now) : "memory");
+            }
+        }
+#else
         for (uint32_t i = lane; i < ncells; i += kWave) g_obj[i] = s_obj[i];
         if (active) {
             const uint32_t world = w0 + wl;
@@ -980,6 +1079,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
                 p.done[world] = kInit ? 0 : (int32_t)reset_now;
             }
         }
+#endif
     };
 
     STAMP(3);
@@ -992,9 +1092,10 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         if (p.patch) {
             // (Encoding and streaming the group in two halves, so that the first half's stores leave while the second is
             // patched, measured slower: 8.6 vs 8.25 us.)
-            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
+            const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
             STAMP(4);
-            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
+            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
+                                     wl, q, posori, held);
             STAMP(5);
         } else
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
@@ -1189,11 +1290,18 @@ constexpr FixedLayout fixed_layout(uint32_t C, uint32_t wpw)
     return f;
 }
 
+// size of a group's holder table (host: hold_table): kHold holder cells per world, round 0 keeps 2 * kW lanes for the players
+constexpr uint32_t fixed_hold_entries(uint32_t wpw, uint32_t holders)
+{
+    const uint32_t free0 = 64u - 2u * wpw, total = wpw * holders;
+    return total == 0 ? 1u : (total <= free0 ? 2u * wpw + total : 64u + (total - free0));
+}
+
 // The step for ONE layout size known at compile time (two players, kC cells, kW worlds per wave, single-pass encode,
 // private constants): every size-dependent kernel argument is replaced by a constant, so divisions by the cell count,
 // loop trip counts and LDS offsets fold (the kernel is bound by instruction issue, not by bytes: section 4.1 of
 // DESIGN.md).  The host launches it only when the simulator's parameters are exactly these; results are identical.
-template <int kC, int kW, int kWidth, int kPots>
+template <int kC, int kW, int kWidth, int kPots, int kHold>
 __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
 {
     constexpr FixedLayout f = fixed_layout(kC, kW);
@@ -1218,6 +1326,8 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     q.tail_even = 1;
     q.private_consts = 1;
     q.terr_entries = kW * 2 * kC;
+    q.direct = 1;
+    q.hold_entries = fixed_hold_entries(kW, kHold);
     q.off_pl = f.off_pl;
     q.off_x = f.off_x;
     q.off_sum = f.off_sum;
@@ -1232,11 +1342,34 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
 }
 
 // kI64: the launch of mrl_step_with_actions_i64 (the int32 one drops the branch on the action pointer too)
-template <int kC, int kW, int kWidth, int kPots, bool kI64 = false>
-__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(const StepParams p)
+// The first fourteen dwords of the argument list (sixteen user SGPRs less the argument-segment pointer) are what a
+// wave needs to find its worlds and request its loads; written as separate scalar arguments they are PRELOADED into
+// SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count=16 in the Makefile; a by-value struct is not
+// eligible), so the first global loads do not wait for a scalar load of the argument segment.  The struct carries
+// everything else (and the same fields again, unused).
+#define MRL_HOT_ARGS                                                                                                      \
+    uint32_t *hot_cell_obj, uint2 *hot_players, int32_t *hot_timestep, const void *hot_actions, const uint32_t *hot_consts, \
+        const uint16_t *hot_terr_off, uint32_t hot_num_worlds, uint32_t hot_per_xcd
+template <bool kI64>
+__device__ __forceinline__ void take_hot_args(StepParams &q, MRL_HOT_ARGS)
 {
-    StepParams q = fixed_params<kC, kW, kWidth, kPots>(p);
-    if (!kI64) q.actions64 = nullptr;
+    q.cell_obj = hot_cell_obj;
+    q.players = hot_players;
+    q.timestep = hot_timestep;
+    q.actions = kI64 ? nullptr : static_cast<const int32_t *>(hot_actions);
+    q.actions64 = kI64 ? static_cast<const long long *>(hot_actions) : nullptr;
+    q.consts = hot_consts;
+    q.terr_off = hot_terr_off;
+    q.num_worlds = hot_num_worlds;
+    q.per_xcd = hot_per_xcd;
+}
+#define MRL_HOT_PASS hot_cell_obj, hot_players, hot_timestep, hot_actions, hot_consts, hot_terr_off, hot_num_worlds, hot_per_xcd
+
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64 = false>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(MRL_HOT_ARGS, const StepParams p)
+{
+    StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
+    take_hot_args<kI64>(q, MRL_HOT_PASS);
     step_body<false, 2>(q);
 }
 
@@ -1278,7 +1411,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
     const uint8_t *s_terrain = private_consts ? smem + kConstBytes + wib * p.lds_wave_stride + p.off_terr : smem + kConstTerrain;
     const uint8_t *s_start = smem + kConstStart;
     const uint8_t *s_pots = smem + kConstPots;
-    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t per_xcd = p.per_xcd;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
@@ -1303,11 +1436,13 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
     uint32_t posori = 0, held = kItemNone;
     int32_t t = 0;
     uint8_t *s_prev = s_flags + 32;  // urgency flags as the tile holds them (wpw * 2 <= 64 players: wpw <= 32)
+    HoldTab hold{};
     {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
         t = p.timestep[world];
         TerrPos tpos;
+        if (p.direct) hold_request(p, lane, hold);
         if (p.patch) {
             terrain_request(p, lane, tpos);
             tile_zero_addtid(s_tile, nw * p.block_bytes);
@@ -1315,7 +1450,8 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
             if (lane < 32) s_prev[lane] = 0;
         }
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (!p.direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (active) {
             posori = pl_reg.x & 0xFFFFu;
             held = pl_reg.y;
@@ -1331,7 +1467,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         __syncthreads();
     }
     if (nw == 0) return;
-    if (active) s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+    if (active && !p.direct) s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
 
     // mrl_step_sequence: the next step's action is requested before this step's encode, so its latency is
     // not in the step-to-step chain
@@ -1367,18 +1503,21 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
             wave_lds_sync();
         }
         // every lane clears its old cell before any lane marks its new one (two DS instructions, in order)
-        if (active) s_cur[old_cell] = 0xFF;
+        if (active && !p.direct) s_cur[old_cell] = 0xFF;
         wave_lds_sync();
         if (active) {
-            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
-            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            if (!p.direct) {
+                reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+                s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            }
             if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
         }
         wave_lds_sync();
         if (p.patch) {
             // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
-            const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
-            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
+            const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
+            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active, wl,
+                                    q, posori, held);
         } else {
             observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
@@ -1406,12 +1545,16 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
 }
 
 // the multi-step launches for one layout size known at compile time (see mrl_overcooked_step_fixed)
-template <int kC, int kW, int kWidth, int kPots>
+template <int kC, int kW, int kWidth, int kPots, int kHold>
 __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout_fixed(const StepParams p, uint32_t num_steps, uint64_t seed,
                                                                                        uint32_t first_step, int32_t *action_out,
                                                                                        const int32_t *action_seq)
 {
-    rollout_body<2>(fixed_params<kC, kW, kWidth, kPots>(p), num_steps, seed, first_step, action_out, action_seq);
+    StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
+    // with the tile and the cell -> player map alive across steps the search costs a multi-step launch little: the table
+    // only where it is one round (measured, cramped_room 16 worlds per wave: 4.46 us per step searched, 4.72 with two rounds)
+    q.direct = fixed_hold_entries(kW, kHold) <= 64u ? 1u : 0u;
+    rollout_body<2>(q, num_steps, seed, first_step, action_out, action_seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1438,7 +1581,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
     uint8_t *wbase = smem + kConstBytes + wib * p.lds_wave_stride;
     const uint8_t *s_terrain = wbase + p.off_terr;
     const uint8_t *s_pots = smem + kConstPots;
-    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t per_xcd = p.per_xcd;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t first_world = (logical_block * kWavesPerBlock + wib) * p.wpw * kG;  // this wave's kG groups are consecutive
     uint32_t *s_obj = reinterpret_cast<uint32_t *>(wbase);
@@ -1485,11 +1628,14 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         a_raw[g] = p.actions64 ? (uint32_t)p.actions64[a_at] : (uint32_t)p.actions[a_at];
         t_reg[g] = p.timestep[min(w0 + wl, N - 1u)];
     }
+    HoldTab hold{};
     {
         const uint32_t nw0 = nw_of[0];  // the first group is the wave's fullest
         TerrPos tpos;
         terrain_request(p, lane, tpos);
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (p.direct) hold_request(p, lane, hold);
+        if (!p.direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         tile_zero_addtid(s_tile, nw0 * p.block_bytes);
         if (lane < 32) s_prev[lane] = 0;
         STAMP(6);
@@ -1535,15 +1681,18 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         }
         if (g == 0) STAMP(2);
         if (active) {
-            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
-            s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            if (!p.direct) {
+                reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+                s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
+            }
             if (q == 0) s_flags[wl] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
         }
         wave_lds_sync();
         if (g == 0) STAMP(3);
-        const uint32_t ndyn = find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
+        const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
         if (g == 0) STAMP(4);
-        observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane);
+        observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active, wl, q,
+                                posori, held);
         if (g == 0) STAMP(5);
         // the group's state, rewards and flags: behind its stream-out, like the ordinary step
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
@@ -1556,7 +1705,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
                 p.timestep[world] = t;
                 p.done[world] = (int32_t)reset_now;
             }
-            if (g + 1 < kG) s_cur[wl * C + (posori & 0xFFu)] = 0xFF;  // the cell -> player map starts the next group empty
+            if (g + 1 < kG && !p.direct) s_cur[wl * C + (posori & 0xFFu)] = 0xFF;  // the cell -> player map starts the next group empty
         }
         wave_lds_sync();
     }
@@ -1564,11 +1713,11 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
     STAMP_REALTIME(14);
 }
 
-template <int kC, int kW, int kWidth, int kPots, bool kI64, int kG>
-__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_groups_fixed(const StepParams p)
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64, int kG>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_groups_fixed(MRL_HOT_ARGS, const StepParams p)
 {
-    StepParams q = fixed_params<kC, kW, kWidth, kPots>(p);
-    if (!kI64) q.actions64 = nullptr;
+    StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
+    take_hot_args<kI64>(q, MRL_HOT_PASS);
     groups_body<2, kG>(q);
 }
 
@@ -1599,10 +1748,11 @@ struct OvercookedSim final : mrl_sim {
     uint32_t H = 0;
     uint32_t grid = 0, lds_bytes = 0;
     bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
-    void (*fixed_kernel)(const StepParams) = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
-    void (*fixed_kernel_i64)(const StepParams) = nullptr;
-    void (*groups_kernel)(const StepParams) = nullptr;      // mrl_overcooked_step_groups_fixed<...>: kGroups groups per wave
-    void (*groups_kernel_i64)(const StepParams) = nullptr;
+    using FixedKernel = void (*)(MRL_HOT_ARGS, const StepParams);
+    FixedKernel fixed_kernel = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
+    FixedKernel fixed_kernel_i64 = nullptr;
+    FixedKernel groups_kernel = nullptr;      // mrl_overcooked_step_groups_fixed<...>: kGroups groups per wave
+    FixedKernel groups_kernel_i64 = nullptr;
     uint32_t groups_grid = 0;
     const char *groups_name = nullptr;
     void (*fixed_rollout)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *) = nullptr;
@@ -1619,13 +1769,17 @@ struct OvercookedSim final : mrl_sim {
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
+        a.per_xcd = ((!init && groups_kernel) ? groups_grid : grid) >> 3;
+        const void *hot_actions = a.actions64 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
         if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (groups_kernel)
-            hipLaunchKernelGGL(a.actions64 ? groups_kernel_i64 : groups_kernel, dim3(groups_grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL(a.actions64 ? groups_kernel_i64 : groups_kernel, dim3(groups_grid), dim3(kBlock), lds_bytes, stream, a.cell_obj,
+                               a.players, a.timestep, hot_actions, a.consts, a.terr_off, a.num_worlds, a.per_xcd, a);
         else if (fixed_kernel)
-            hipLaunchKernelGGL(a.actions64 ? fixed_kernel_i64 : fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL(a.actions64 ? fixed_kernel_i64 : fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a.cell_obj, a.players,
+                               a.timestep, hot_actions, a.consts, a.terr_off, a.num_worlds, a.per_xcd, a);
         else if (a.P == 2 && !generic)
             hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
@@ -1928,6 +2082,43 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
             wpw >>= 1;
         sim->lds_bytes = layout(wpw) + (uint32_t)mrl::debug_get("overcooked.lds_pad", 0);  // the pad: residency experiments
+        // p.direct (patch_direct): holder cells = counters / pots next to a walkable cell; players must start on walkable cells
+        std::vector<uint32_t> holders;  // cell | is_pot << 8
+        for (int64_t c = 0; c < C; c++) {
+            const uint32_t t = consts[kConstTerrain + c];
+            if (t != T_COUNTER && t != T_POT) continue;
+            const int64_t x = c % W, y = c / W;
+            bool faced = false;
+            if (x > 0 && consts[kConstTerrain + c - 1] == T_AIR) faced = true;
+            if (x + 1 < W && consts[kConstTerrain + c + 1] == T_AIR) faced = true;
+            if (y > 0 && consts[kConstTerrain + c - W] == T_AIR) faced = true;
+            if (y + 1 < H && consts[kConstTerrain + c + W] == T_AIR) faced = true;
+            if (faced) holders.push_back((uint32_t)c | (t == T_POT ? 0x100u : 0u));
+        }
+        // table of a group of `gw` worlds: round 0 keeps lanes [0, gw * P) for the players
+        auto hold_table = [&](uint32_t gw) {
+            std::vector<uint32_t> tab;
+            const uint32_t free0 = (uint32_t)kWave - std::min<uint32_t>((uint32_t)kWave, gw * a.P);
+            uint32_t s = 0;
+            for (uint32_t l = 0; l < gw; l++)
+                for (const uint32_t h : holders) {
+                    const uint32_t c = h & 0xFFu;
+                    const uint32_t slot = s < free0 ? gw * a.P + s : (uint32_t)kWave + (s - free0);
+                    if (tab.size() <= slot) tab.resize(slot + 1, 0u);
+                    tab[slot] = (l * a.block_bytes + c * a.F) | ((l * a.C + c) << 16) | (1u << 30) | ((h >> 8) << 31);
+                    s++;
+                }
+            if (tab.empty()) tab.resize(1, 0u);
+            return tab;
+        };
+        {
+            bool starts_walkable = true;
+            for (int64_t q = 0; q < P; q++) starts_walkable = starts_walkable && consts[kConstTerrain + consts[kConstStart + q]] == T_AIR;
+            a.direct = (a.patch && starts_walkable && hold_table(a.wpw).size() <= (size_t)kHoldPerLane * kWave &&
+                        !mrl::debug_get("overcooked.no_direct", 0))
+                           ? 1u
+                           : 0u;
+        }
         if (sim->lds_bytes > 65536) {
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
@@ -1948,23 +2139,23 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= (uint32_t)mrl::debug_get("overcooked.share_max_players", 64) && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
         {
             // a kernel specialised for this layout size, if there is one and the parameters are exactly what it assumes
-            auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_) {
+            auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_, uint32_t hold_) {
                 const FixedLayout f = fixed_layout(C_, wpw_);
                 return a.P == 2 && !sim->generic && a.C == C_ && a.W == width_ && a.num_pots == pots_ && a.wpw == wpw_ && a.whole &&
-                       a.patch && !a.share && a.private_consts && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
+                       a.patch && a.direct && holders.size() == hold_ && !a.share && a.private_consts && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
                        a.off_cur == f.off_cur && a.off_flags == f.off_flags && a.off_terr == f.off_terr && a.off_list == f.off_list &&
                        a.off_tile == f.off_tile && a.lds_wave_stride == f.stride && !mrl::debug_get("overcooked.no_fixed", 0);
             };
-#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                          \
-    if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_)) {                                                   \
-        sim->fixed_kernel = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_>;                                    \
-        sim->fixed_kernel_i64 = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, true>;                          \
-        sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                \
-        sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", false>";                 \
+#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_, HOLD_)                                                                          \
+    if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_, HOLD_)) {                                                   \
+        sim->fixed_kernel = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                    \
+        sim->fixed_kernel_i64 = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>;                          \
+        sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                \
+        sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false>";      \
         if (groups == 2) {                                                                                          \
-            sim->groups_kernel = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, false, 2>;              \
-            sim->groups_kernel_i64 = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, true, 2>;           \
-            sim->groups_name = "mrl_overcooked_step_groups_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", false, 2>"; \
+            sim->groups_kernel = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, 2>;              \
+            sim->groups_kernel_i64 = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, 2>;           \
+            sim->groups_name = "mrl_overcooked_step_groups_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false, 2>"; \
         }                                                                                                           \
     }
             // Groups of worlds a wave steps one after the other in the single step (mrl_overcooked_step_groups_fixed).
@@ -1977,15 +2168,17 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             const uint64_t ngroups = ((uint64_t)N + wpw - 1) / wpw;
             const int64_t groups = groups_knob ? groups_knob : ((ngroups >= 12288 && ngroups <= 65536) ? 2 : 1);
             // the five standard layouts: cells, worlds per wave, grid width, pots
-            MRL_FIXED(20, 8, 5, 1)   // cramped_room
-            MRL_FIXED(45, 4, 9, 2)   // asymmetric_advantages
-            MRL_FIXED(25, 4, 5, 2)   // coordination_ring, forced_coordination
-            MRL_FIXED(40, 4, 8, 2)   // counter_circuit
+            // the five standard layouts: cells, worlds per wave, grid width, pots, holder cells
+            MRL_FIXED(20, 8, 5, 1, 6)    // cramped_room
+            MRL_FIXED(45, 4, 9, 2, 14)   // asymmetric_advantages
+            MRL_FIXED(25, 4, 5, 2, 9)    // coordination_ring, forced_coordination
+            MRL_FIXED(40, 4, 8, 2, 18)   // counter_circuit
 #undef MRL_FIXED
         }
         const uint32_t waves = a.share ? N * kWavesPerBlock : (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
+        a.per_xcd = sim->grid >> 3;  // launch() sets it again per launch (the two-groups kernels have their own grid)
         if (sim->groups_kernel) {
             const uint32_t gwaves = (waves + 1u) / 2u;
             sim->groups_grid = ((gwaves + kWavesPerBlock - 1) / kWavesPerBlock + 7u) & ~7u;
@@ -2018,26 +2211,37 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             MRL_HIP(hipMemcpy(d_off, off.data(), a.terr_entries * sizeof(uint16_t), hipMemcpyHostToDevice));
             a.terr_off = d_off;
         }
+        auto upload_hold = [&](StepParams &dst, uint32_t gw) {
+            const std::vector<uint32_t> tab = hold_table(gw);
+            uint32_t *d_tab = sim->arena.alloc<uint32_t>(tab.size(), false);
+            MRL_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            dst.hold_tab = d_tab;
+            dst.hold_entries = (uint32_t)tab.size();
+        };
+        upload_hold(a, a.wpw);
         // Multi-step launches of the standard layouts: groups twice as wide where the table of terrain offsets and the
         // LDS of two workgroups per CU allow (measured in DESIGN.md 4.1; mrl_debug_set overcooked.wide_rollout 1 = never)
         if (sim->fixed_rollout && mrl::debug_get("overcooked.wide_rollout", 0) != 1) {
             const uint32_t rw = 2u * a.wpw;
             uint32_t stride = 0;
-#define MRL_WIDE(C_, W2_, WIDTH_, POTS_)                                                                             \
-    if (!sim->wide_rollout && a.C == C_ && rw == W2_ && a.W == WIDTH_ && a.num_pots == POTS_) {                      \
-        sim->wide_rollout = &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_>;                                  \
+#define MRL_WIDE(C_, W2_, WIDTH_, POTS_, HOLD_)                                                                             \
+    if (!sim->wide_rollout && a.C == C_ && rw == W2_ && a.W == WIDTH_ && a.num_pots == POTS_ && holders.size() == HOLD_) {                      \
+        sim->wide_rollout = &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_>;                                  \
         stride = fixed_layout(C_, W2_).stride;                                                                      \
     }
-            MRL_WIDE(20, 16, 5, 1)  // cramped_room
-            MRL_WIDE(25, 8, 5, 2)   // coordination_ring, forced_coordination
-            MRL_WIDE(40, 8, 8, 2)   // counter_circuit
+            MRL_WIDE(20, 16, 5, 1, 6)  // cramped_room
+            MRL_WIDE(25, 8, 5, 2, 9)   // coordination_ring, forced_coordination
+            MRL_WIDE(40, 8, 8, 2, 18)  // counter_circuit
 #undef MRL_WIDE
             const uint32_t wide_waves = (N + rw - 1) / rw;
-            if (sim->wide_rollout && (rw * a.rows > (uint32_t)kTerrPosPerLane * kWave || wide_waves < 2048u)) sim->wide_rollout = nullptr;
+            if (sim->wide_rollout && (rw * a.rows > (uint32_t)kTerrPosPerLane * kWave || wide_waves < 2048u ||
+                                      hold_table(rw).size() > (size_t)kHoldPerLane * kWave))
+                sim->wide_rollout = nullptr;
             if (sim->wide_rollout) {
                 sim->wide_params = a;
                 sim->wide_lds = kConstBytes + kWavesPerBlock * stride;
                 sim->wide_grid = (((wide_waves + kWavesPerBlock - 1) / kWavesPerBlock) + 7u) & ~7u;
+                sim->wide_params.per_xcd = sim->wide_grid >> 3;
                 std::vector<uint16_t> off((size_t)rw * a.rows, 0);
                 for (uint32_t l = 0; l < rw; l++)
                     for (uint32_t v = 0; v < a.P; v++)
@@ -2048,6 +2252,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
                 uint16_t *d_off = sim->arena.alloc<uint16_t>(off.size(), false);
                 MRL_HIP(hipMemcpy(d_off, off.data(), off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
                 sim->wide_params.terr_off = d_off;
+                upload_hold(sim->wide_params, rw);
                 if (sim->wide_lds > 65536)
                     MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sim->wide_rollout), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)sim->wide_lds));

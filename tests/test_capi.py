@@ -53,7 +53,8 @@ def test_debug_knobs_are_an_explicit_call_not_the_environment(hip_lib):
         _lib.debug_set("overcooked.typo", 1)
     csrc = os.path.join(REPO, "madrona_rl_envs_playground_amd", "csrc")
     for f in os.listdir(csrc):
-        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+        if os.path.isfile(os.path.join(csrc, f)):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_abi_version_mismatch_is_refused(hip_lib, monkeypatch):

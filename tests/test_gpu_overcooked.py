@@ -146,6 +146,40 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
     generic.close()
 
 
+@pytest.mark.parametrize("layout,cap,n", [("cramped_room", None, 4099), ("counter_circuit", None, 1001), ("asymmetric_advantages", None, 515),
+                                          ("multiplayer_schelling", None, 130), ("cramped_room", None, 7)])
+def test_direct_patch_equals_searched(layout, cap, n, hip_lib):
+    """The single-pass encode takes its dynamic rows from the player lanes and a table of holder cells (counters and pots a
+    player can face); `overcooked.no_direct` makes it look for them through the cell -> player map instead.  Same tensors,
+    through the generic kernels, the multi-step launches included."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params(layout, 45, max_num_players=cap)
+    P = params["num_players"]
+    with debug_knobs({"overcooked.no_fixed": 1}):
+        direct = make_sim(params, n)
+    with debug_knobs({"overcooked.no_fixed": 1, "overcooked.no_direct": 1}):
+        searched = make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for t in range(120):
+        if t % 3 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            a[torch.rand((P, n, 1), device="cuda", generator=gen) < 0.3] = 5
+            direct.step_with_actions(a)
+            searched.step_with_actions(a)
+        elif t % 3 == 1:
+            direct.rollout_random(3, seed=5, first_step=3 * t)
+            searched.rollout_random(3, seed=5, first_step=3 * t)
+        else:
+            seq = torch.randint(0, 6, (4, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            direct.step_sequence(seq)
+            searched.step_sequence(seq)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(direct, get)().to_torch(), getattr(searched, get)().to_torch()), f"{get}, step {t}"
+    direct.close()
+    searched.close()
+
+
 @pytest.mark.parametrize("layout,n,wpw", [("cramped_room", 4099, 8), ("cramped_room", 40003, 0), ("asymmetric_advantages", 16391, 0),
                                           ("counter_circuit", 1001, 4), ("coordination_ring", 24581, 0)])
 def test_two_groups_per_wave_equals_one(layout, n, wpw, hip_lib):
