@@ -375,7 +375,7 @@ __device__ __forceinline__ uint32_t swap_pair(uint32_t v)
 
 // The transition of a whole group at once: lane = (world wl of the group, player q), lane = wl*P + q
 // (sim.cpp:199-438).  `posori` = pos | orientation << 8 and `held` are the lane's own player in
-// registers; the cells' objects are in LDS (s_obj, [wpw][C]).  kP == 2: pairs exchange through DPP;
+// registers; the cells' objects are in LDS (obj_w = the C cells of the lane's world).  kP == 2: pairs exchange through DPP;
 // kP == 0: any player count, through the scratch arrays s_x (>= 128 words), s_sum, s_blk (one word per world).
 //   interactions  sources and the serving window touch nobody else's state.  Counter / pot
 //                 interactions on the same cell happen in ascending player id: a player's RANK is the
@@ -387,11 +387,10 @@ __device__ __forceinline__ uint32_t swap_pair(uint32_t v)
 // Inactive lanes (beyond the group's players) run along with harmless values.  Returns the
 // reward of the lane's WORLD (summed over its players) through reward_world.
 template <int kP>
-__device__ __forceinline__ void transition_lanes(const StepParams &p, const uint8_t *s_terrain, uint32_t *s_obj, uint32_t *s_x,
+__device__ __forceinline__ void transition_lanes(const StepParams &p, const uint8_t *s_terrain, uint32_t *obj_w, uint32_t *s_x,
                                                  uint32_t *s_sum, uint32_t *s_blk, uint32_t P, uint32_t lane, bool active, uint32_t wl,
                                                  uint32_t q, uint32_t a, uint32_t &posori, uint32_t &held, int32_t &reward_world)
 {
-    const uint32_t C = p.C;
     const uint32_t pos = posori & 0xFFu, ori = (posori >> 8) & 0xFFu;
     const uint32_t tgt = pos + (uint32_t)step_of(ori, p.deltas);
     const uint32_t terr = s_terrain[tgt];
@@ -412,7 +411,7 @@ __device__ __forceinline__ void transition_lanes(const StepParams &p, const uint
     }
     int32_t mine = 0;
     const int32_t value = (int32_t)lookup16(p.values_w, recipe_of(held));
-    uint32_t *cell = s_obj + (touches ? wl * C + tgt : 0u);
+    uint32_t *cell = obj_w + (touches ? tgt : 0u);  // obj_w: the cells of the lane's world
     constexpr uint32_t kRounds = kP == 2 ? 2u : 4u;  // at most four players face one cell
     // one copy of the interaction code for all rounds (rounds after the first are rare and the launch is sensitive to
     // the size of its straight-line code: DESIGN.md 4.1)
@@ -465,10 +464,9 @@ __device__ __forceinline__ void transition_lanes(const StepParams &p, const uint
 }
 
 // Pots (sim.cpp:430-438), after the interactions: a pot started in this step is already at 1.  Lane = world.
-__device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_pots, uint32_t *s_obj, uint32_t nw, uint32_t lane)
+__device__ __forceinline__ void tick_pots_world(const StepParams &p, const uint8_t *s_pots, uint32_t *obj, bool valid)
 {
-    if (lane < nw) {
-        uint32_t *obj = s_obj + lane * p.C;
+    if (valid) {
         for (uint32_t k = 0; k < p.num_pots; k++) {
             const uint32_t c = k < 4 ? (p.pots_w >> (8 * k)) & 0xFFu : (uint32_t)s_pots[k];
             const uint32_t o = obj[c];
@@ -477,6 +475,10 @@ __device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_
                 obj[c] = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
         }
     }
+}
+__device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_pots, uint32_t *s_obj, uint32_t nw, uint32_t lane)
+{
+    tick_pots_world(p, s_pots, s_obj + lane * p.C, lane < nw);
 }
 // Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
@@ -1019,7 +1021,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     bool reset_now = kInit;
     if (!kInit) {
         if (!ABLATED(4)) {
-            transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
+            transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
             tick_pots(p, s_pots, s_obj, nw, lane);
         }
         // horizon (sim.cpp:485-489)
@@ -1486,7 +1488,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         if (!active) a = A_STAY;
         const uint32_t old_cell = wl * C + (posori & 0xFFu);
         int32_t reward_world = 0;
-        transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, a, posori, held, reward_world);
+        transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, a, posori, held, reward_world);
         tick_pots(p, s_pots, s_obj, nw, lane);
         t += 1;
         const bool reset_now = (int64_t)t >= p.horizon;
@@ -1663,7 +1665,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         wave_lds_sync();
         if (g == 0) STAMP(1);
         int32_t reward_world = 0;
-        transition_lanes<kP>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
+        transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
         tick_pots(p, s_pots, s_obj, nw, lane);
         int32_t t = t_reg[g] + 1;
         const bool reset_now = (int64_t)t >= p.horizon;
