@@ -73,6 +73,14 @@ struct SimpleParams {
     uint32_t flat;
     const uint16_t *terr_off;  // [wpw * rows]: tile offset of a group row's terrain byte, 0 = none
     uint32_t terr_entries;
+    // direct (the single step of flat two-player groups): the dynamic rows come from the player lanes and a host-built
+    // table of the group's HOLDER cells (counters and pots a player can face) instead of a search -- overcooked.hip,
+    // patch_direct.  Entry [k * 64 + lane]: tile offset of the cell's viewer-0 row | cell index in the group << 16 |
+    // 1 << 30 | is_pot << 31; the lanes below wpw * P of round 0 are left to the players.
+    uint32_t direct;
+    const uint32_t *hold_tab;
+    uint32_t hold_entries;
+    uint32_t per_xcd;  // workgroups of the launch / 8
     uint32_t *cell_obj;
     uint2 *players;
     int2 *clock;  // {timestep, num_dishes_out}
@@ -262,6 +270,7 @@ __device__ __forceinline__ void lds_store_tail10_bytes(uint8_t *ptr, const Tail1
     ptr[9] = (uint8_t)(t.c >> 8);
 }
 
+constexpr int kHoldPerLane = 4;     // 256 holder-table entries per group (direct)
 constexpr int kTerrPosPerLane = 4;  // rows of one world <= 2 * 100
 constexpr int kGroupTerrPerLane = 7;  // rows of one GROUP in the flat mode (the standard layouts need 320..400)
 
@@ -278,7 +287,7 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
     const uint8_t *s_pots = smem + kConstPots;
 
     // XCD-aware mapping: one contiguous world range per XCD (workgroups are dealt round-robin)
-    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t per_xcd = p.per_xcd;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
@@ -302,6 +311,14 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
     int2 clock = make_int2(0, 0);
     uint32_t tpos[kTerrPosPerLane];
     uint32_t goff[kGroupTerrPerLane];
+    uint32_t hold[kHoldPerLane] = {};
+    const bool direct = kP == 2 && p.direct != 0;
+    auto hold_request = [&]() {
+        const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.hold_tab), 0, (int)(p.hold_entries * 4u), 0x00020000);
+#pragma unroll
+        for (int k = 0; k < kHoldPerLane; k++)
+            hold[k] = (uint32_t)k * kWave < p.hold_entries ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(tab, (int)((lane + (uint32_t)k * kWave) * 4u), 0, 0) : 0u;
+    };
     auto static_request = [&]() {
         if (p.flat) {
             const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.terr_off), 0, (int)(p.terr_entries * 2u), 0x00020000);
@@ -341,8 +358,10 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         clock = p.clock[world];
         static_request();
         // while the loads are in flight: empty cell -> player map, zeroed tile
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (!direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         static_zero();
+        if (direct) hold_request();
 #pragma unroll
         for (int k = 0; k < kBatch; k++) {
             const uint32_t i = lane + k * kWave;
@@ -355,8 +374,10 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         if ((p.sample || p.actions64) && active) p.action_out[(size_t)q * N + world] = (int32_t)(p.sample ? act : a_raw);
     } else {
         static_request();
-        for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
+        if (!direct)
+            for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         static_zero();
+        if (direct) hold_request();
     }
     // the group's slab in HBM and its image in the tile are equally misaligned, so 16-byte chunks line up
     uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
@@ -404,15 +425,47 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
             if (s_list[__umulhi(i, p.inv_c)] != 0) s_obj[i] = kItemNone;
         wave_lds_sync();
     }
-    if (active) {
+    if (active && !direct) {
         reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
         s_cur[wl * C + (posori & 0xFFu)] = (uint8_t)q;
     }
     wave_lds_sync();
 
     // ---------------- observe: only the dynamic cells (sim.cpp:62-148) ----------------
+    const uint32_t plane = __umul24(C, F), shift = 5 * P;
+    if constexpr (kP == 2) {
+        if (direct) {
+            // players stand on AIR cells only and objects lie on holder cells only: lane = a player's cell (round 0) or a
+            // holder cell; its 10-byte tail goes into the rows of both viewers
+            const uint32_t ori = (posori >> 8) & 0xFFu;
+#pragma unroll
+            for (int k = 0; k < kHoldPerLane; k++) {
+                if (k > 0 && (uint32_t)k * kWave >= p.hold_entries) break;  // wave-uniform
+                const uint32_t e = hold[k];
+                const uint32_t i = (e >> 16) & 0x3FFFu;
+                const bool holder = ((e >> 30) & 1u) != 0u && i < ncells;
+                const uint32_t o = s_obj[holder ? i : 0u];
+                const bool player = k == 0 && active;
+                if (player || (holder && (o & 0xFFu) != O_NONE)) {
+                    const Tail10 t10 = cell_tail(player ? (uint32_t)T_AIR : ((e >> 31) ? (uint32_t)T_POT : (uint32_t)T_COUNTER),
+                                                 player ? (uint32_t)kItemNone : o, player ? held : (uint32_t)kItemNone);
+                    uint8_t *row0 = tile + (player ? __umul24(wl, p.block_bytes) + __umul24(posori & 0xFFu, F) : (e & 0xFFFFu));
+#pragma unroll
+                    for (uint32_t v = 0; v < 2; v++) {
+                        uint8_t *row = row0 + v * plane;
+                        lds_store_tail10_p2(row + shift, t10);
+                        if (player) {
+                            const uint32_t rel = q == v ? 0u : 1u;
+                            row[rel] = 1;
+                            row[P + 4 * rel + ori] = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
     uint32_t ndyn = 0;
-    for (uint32_t i0 = 0; i0 < ncells; i0 += kWave) {
+    for (uint32_t i0 = 0; i0 < (direct ? 0u : ncells); i0 += kWave) {
         const uint32_t i = i0 + lane;
         const bool valid = i < ncells;
         const uint32_t o = s_obj[valid ? i : 0u];
@@ -424,7 +477,6 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         ndyn += (uint32_t)__popcll(m);
     }
     wave_lds_sync();
-    const uint32_t plane = __umul24(C, F), shift = 5 * P;
     const uint32_t nent = ndyn * P;
     for (uint32_t j = lane; j < nent; j += kWave) {
         const uint32_t k = kP == 2 ? j >> 1 : j, v = kP == 2 ? j & 1u : 0u;
@@ -492,7 +544,13 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimplePara
 // and LDS offsets fold -- the kernel is bound by instruction issue, not by bytes.  Launched only when
 // the simulator's parameters are exactly these; results are identical.
 constexpr uint32_t up16c(uint32_t v) { return (v + 15u) & ~15u; }
-template <int kC, int kW, int kWidth, int kPots>
+// size of a group's holder table: kHold holder cells per world, round 0 keeps 2 * kW lanes for the players
+constexpr uint32_t fixed_hold_entries(uint32_t wpw, uint32_t holders)
+{
+    const uint32_t free0 = 64u - 2u * wpw, total = wpw * holders;
+    return total == 0 ? 1u : (total <= free0 ? 2u * wpw + total : 64u + (total - free0));
+}
+template <int kC, int kW, int kWidth, int kPots, int kHold>
 __device__ __forceinline__ SimpleParams fixed_simple_params(const SimpleParams &p)
 {
     SimpleParams q = p;
@@ -513,16 +571,31 @@ __device__ __forceinline__ SimpleParams fixed_simple_params(const SimpleParams &
     q.off_tile = q.off_list + up16c(kW * kC * 2 > 128 ? kW * kC * 2 : 128);
     q.flat = 1;  // (kW * 2 * kC * 20) % 16 == 0 for the four sizes below
     q.terr_entries = kW * 2 * kC;
+    q.direct = 1;
+    q.hold_entries = fixed_hold_entries(kW, kHold);
     q.lds_wave_stride = q.off_tile + ((kW * 2 * kC * 20 + 255u) & ~255u) + 48u;
     return q;
 }
 
 // kSource: where the actions come from -- 0 the int32 array, 1 the caller's int64 tensor, 2 drawn in the kernel
-template <int kC, int kW, int kWidth, int kPots, int kSource = 0>
-__global__ void __launch_bounds__(kBlock) mrl_simplecooked_step_fixed(const SimpleParams p)
+// The first fourteen argument dwords are separate scalars so that the command processor preloads them into SGPRs
+// (-amdgpu-kernarg-preload-count in the Makefile; overcooked.hip, MRL_HOT_ARGS): what a wave needs to find its worlds
+// and request its loads.  The struct carries everything else.
+template <int kC, int kW, int kWidth, int kPots, int kHold, int kSource = 0>
+__global__ void __launch_bounds__(kBlock)
+    mrl_simplecooked_step_fixed(uint32_t *hot_cell_obj, uint2 *hot_players, int2 *hot_clock, const void *hot_actions, const uint32_t *hot_consts,
+                                const uint16_t *hot_terr_off, uint32_t hot_num_worlds, uint32_t hot_per_xcd, const SimpleParams p)
 {
-    SimpleParams q = fixed_simple_params<kC, kW, kWidth, kPots>(p);
-    if (kSource != 1) q.actions64 = nullptr;
+    SimpleParams q = fixed_simple_params<kC, kW, kWidth, kPots, kHold>(p);
+    q.cell_obj = hot_cell_obj;
+    q.players = hot_players;
+    q.clock = hot_clock;
+    q.actions = kSource == 0 ? static_cast<const int32_t *>(hot_actions) : nullptr;
+    q.actions64 = kSource == 1 ? static_cast<const long long *>(hot_actions) : nullptr;
+    q.consts = hot_consts;
+    q.terr_off = hot_terr_off;
+    q.num_worlds = hot_num_worlds;
+    q.per_xcd = hot_per_xcd;
     if (kSource != 2) q.sample = 0;
     step_body<false, 2>(q);
 }
@@ -545,7 +618,7 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
     const uint32_t const_word = tid < kConstBytes / 4 ? p.consts[tid] : 0u;
     const uint8_t *s_terrain = smem + kConstTerrain;
     const uint8_t *s_pots = smem + kConstPots;
-    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t per_xcd = p.per_xcd;
     const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     const uint32_t w0 = (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
@@ -708,11 +781,11 @@ __global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout(const SimpleP
     rollout_body(p, num_steps, seed, first_step, action_seq);
 }
 
-template <int kC, int kW, int kWidth, int kPots>
+template <int kC, int kW, int kWidth, int kPots, int kHold>
 __global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout_fixed(const SimpleParams p, uint32_t num_steps, uint64_t seed,
                                                                          uint32_t first_step, const int32_t *action_seq)
 {
-    rollout_body(fixed_simple_params<kC, kW, kWidth, kPots>(p), num_steps, seed, first_step, action_seq);
+    rollout_body(fixed_simple_params<kC, kW, kWidth, kPots, kHold>(p), num_steps, seed, first_step, action_seq);
 }
 
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
@@ -733,7 +806,8 @@ __global__ void fill_i32(int32_t *dst, int32_t value, size_t count)
 struct SimplecookedSim final : mrl_sim {
     SimpleParams params{};
     uint32_t H = 0, grid = 0, lds_bytes = 0;
-    void (*fixed_kernel[3])(const SimpleParams) = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
+    using FixedKernel = void (*)(uint32_t *, uint2 *, int2 *, const void *, const uint32_t *, const uint16_t *, uint32_t, uint32_t, const SimpleParams);
+    FixedKernel fixed_kernel[3] = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
     void (*fixed_rollout)(const SimpleParams, uint32_t, uint64_t, uint32_t, const int32_t *) = nullptr;
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
@@ -747,7 +821,10 @@ struct SimplecookedSim final : mrl_sim {
             else
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else if (fixed_kernel[0]) {
-            hipLaunchKernelGGL(fixed_kernel[a.sample ? 2 : (a.actions64 ? 1 : 0)], dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            const int source = a.sample ? 2 : (a.actions64 ? 1 : 0);
+            const void *hot_actions = source == 1 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
+            hipLaunchKernelGGL(fixed_kernel[source], dim3(grid), dim3(kBlock), lds_bytes, stream, a.cell_obj, a.players, a.clock, hot_actions,
+                               a.consts, a.terr_off, a.num_worlds, a.per_xcd, a);
         } else if (a.P == 2) {
             hipLaunchKernelGGL((mrl_simplecooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else {
@@ -978,20 +1055,52 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.terr_entries = wpw * a.rows;
         a.lds_wave_stride = a.off_tile + (a.flat ? ((wpw * a.block_bytes + 255u) & ~255u) : up16(wpw * a.block_bytes)) + 48u;
         sim->lds_bytes = kConstBytes + kWavesPerBlock * a.lds_wave_stride;
-#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_)                                                                                          \
-    if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ && a.flat &&             \
-        !mrl::debug_get("overcooked.no_fixed", 0)) {                                                                                 \
-        sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 0>;                                             \
-        sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 1>;                                             \
-        sim->fixed_kernel[2] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, 2>;                                             \
-        sim->fixed_rollout = &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_>;                                               \
-        sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", 0>";                             \
+        // direct encode (see SimpleParams): holder cells = counters / pots next to a walkable cell; players start on walkable cells
+        std::vector<uint32_t> holders;  // cell | is_pot << 8
+        for (int64_t c = 0; c < C; c++) {
+            const uint32_t t = consts[kConstTerrain + c];
+            if (t != T_COUNTER && t != T_POT) continue;
+            const int64_t x = c % W, y = c / W;
+            const bool faced = (x > 0 && consts[kConstTerrain + c - 1] == T_AIR) || (x + 1 < W && consts[kConstTerrain + c + 1] == T_AIR) ||
+                               (y > 0 && consts[kConstTerrain + c - W] == T_AIR) || (y + 1 < H && consts[kConstTerrain + c + W] == T_AIR);
+            if (faced) holders.push_back((uint32_t)c | (t == T_POT ? 0x100u : 0u));
+        }
+        std::vector<uint32_t> hold_tab;
+        {
+            const uint32_t free0 = (uint32_t)kWave - std::min<uint32_t>((uint32_t)kWave, wpw * a.P);
+            uint32_t k = 0;
+            for (uint32_t l = 0; l < wpw; l++)
+                for (const uint32_t h : holders) {
+                    const uint32_t c = h & 0xFFu;
+                    const uint32_t slot = k < free0 ? wpw * a.P + k : (uint32_t)kWave + (k - free0);
+                    if (hold_tab.size() <= slot) hold_tab.resize(slot + 1, 0u);
+                    hold_tab[slot] = (l * a.block_bytes + c * a.F) | ((l * a.C + c) << 16) | (1u << 30) | ((h >> 8) << 31);
+                    k++;
+                }
+            if (hold_tab.empty()) hold_tab.resize(1, 0u);
+            bool starts_walkable = true;
+            for (int64_t q = 0; q < P; q++) starts_walkable = starts_walkable && consts[kConstTerrain + ((starts >> (8 * q)) & 0xFFu)] == T_AIR;
+            a.direct = (a.P == 2 && a.flat && starts_walkable && hold_tab.size() <= (size_t)kHoldPerLane * kWave && wpw * a.block_bytes < 65536u &&
+                        !mrl::debug_get("overcooked.no_direct", 0))
+                           ? 1u
+                           : 0u;
+            a.hold_entries = (uint32_t)hold_tab.size();
+        }
+#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_, HOLD_)                                                                                   \
+    if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ && a.flat && a.direct && \
+        holders.size() == HOLD_ && !mrl::debug_get("overcooked.no_fixed", 0)) {                                                      \
+        sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 0>;                                      \
+        sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 1>;                                      \
+        sim->fixed_kernel[2] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 2>;                                      \
+        sim->fixed_rollout = &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                        \
+        sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", 0>";                 \
     }
-        // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave
-        MRL_FIXED(20, 8, 5, 1)   // simple
-        MRL_FIXED(45, 4, 9, 2)   // unident_s
-        MRL_FIXED(25, 8, 5, 2)   // random0, random1
-        MRL_FIXED(40, 4, 8, 2)   // random3
+        // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave: cells, worlds per wave,
+        // grid width, pots, holder cells
+        MRL_FIXED(20, 8, 5, 1, 6)    // simple
+        MRL_FIXED(45, 4, 9, 2, 14)   // unident_s
+        MRL_FIXED(25, 8, 5, 2, 9)    // random0, random1
+        MRL_FIXED(40, 4, 8, 2, 18)   // random3
 #undef MRL_FIXED
         if (sim->lds_bytes > 65536) {
             set_error("simplecooked: internal: %u bytes of LDS per workgroup", sim->lds_bytes);
@@ -1000,6 +1109,12 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         const uint32_t waves = (N + wpw - 1) / wpw;
         const uint32_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
         sim->grid = (blocks + 7u) & ~7u;
+        a.per_xcd = sim->grid >> 3;
+        {
+            uint32_t *d_tab = sim->arena.alloc<uint32_t>(hold_tab.size(), false);
+            MRL_HIP(hipMemcpy(d_tab, hold_tab.data(), hold_tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            a.hold_tab = d_tab;
+        }
 
         uint32_t *d_consts = sim->arena.alloc<uint32_t>(kConstBytes / 4, false);
         MRL_HIP(hipMemcpy(d_consts, consts, kConstBytes, hipMemcpyHostToDevice));

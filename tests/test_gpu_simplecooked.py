@@ -131,6 +131,30 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
     generic.close()
 
 
+@pytest.mark.parametrize("layout,n", [("simple", 4099), ("random0", 1030), ("unident_s", 7)])
+def test_direct_patch_equals_searched(layout, n, hip_lib):
+    """The single step takes its dynamic rows from the player lanes and a table of holder cells; `overcooked.no_direct`
+    makes it look for them through the cell -> player map.  Same tensors (generic kernels, interact-heavy actions)."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_simplecooked_layout_params(layout, 37)
+    P = params["num_players"]
+    with debug_knobs({"overcooked.no_fixed": 1}):
+        direct = make_sim(params, n)
+    with debug_knobs({"overcooked.no_fixed": 1, "overcooked.no_direct": 1}):
+        searched = make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(120):
+        a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+        a[torch.rand((P, n, 1), device="cuda", generator=gen) < 0.3] = 5
+        direct.step_with_actions(a)
+        searched.step_with_actions(a)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(direct, get)().to_torch(), getattr(searched, get)().to_torch()), f"{get}, step {t}"
+    direct.close()
+    searched.close()
+
+
 def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
     """mrl_rollout_random draws the documented stream (all steps of a call in one launch, state and tile resident);
     mrl_step_sequence runs an action array the same way; both equal the oracle and one launch per step."""
