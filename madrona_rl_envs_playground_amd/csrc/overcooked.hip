@@ -721,7 +721,7 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     {
         const uint32_t mine = lane < nl ? s_flags[l0 + lane] : 0u;
         const uint32_t had = (kRestore && lane < nl) ? s_prev[l0 + lane] : 0u;
-        if (__ballot(mine != had) != 0ull) {
+        if (__builtin_expect(__ballot(mine != had) != 0ull, 0)) {
             const uint32_t nrows = (l0 + nl) * p.rows;
             for (uint32_t r = l0 * p.rows + lane; r < nrows; r += kWave) {
                 const uint32_t l = __umulhi(r, p.inv_rows);
@@ -881,6 +881,16 @@ __device__ __forceinline__ void tile_zero_addtid(uint8_t *tile, uint32_t nbytes)
 #define ABLATED(bit) false
 #endif
 
+// Action `at` of the caller's array: int32, or int64 narrowed to its low word -- only that word is loaded (an 8-byte
+// load whose upper half is dead made hipcc wait for ALL outstanding loads before reusing the register: 0.45 us).
+// One base pointer and a shift rather than a select between two element loads.
+__device__ __forceinline__ uint32_t load_action(const StepParams &p, size_t at)
+{
+    const bool wide = p.actions64 != nullptr;
+    const char *base = wide ? reinterpret_cast<const char *>(p.actions64) : reinterpret_cast<const char *>(p.actions);
+    return *reinterpret_cast<const uint32_t *>(base + (at << (wide ? 3 : 2)));
+}
+
 template <bool kInit, int kP>
 __device__ __forceinline__ void step_body(const StepParams &p)
 {
@@ -964,7 +974,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         const auto pl_raw = __builtin_amdgcn_raw_buffer_load_b64(r_pl, (int)(lane * 8u), 0, 0);
         const uint2 pl_reg = make_uint2(pl_raw[0], pl_raw[1]);
         const size_t a_at = (size_t)(active ? q : 0u) * N + min(w0 + wl, N - 1u);
-        const uint32_t a_raw = p.actions64 ? (uint32_t)p.actions64[a_at] : (uint32_t)p.actions[a_at];
+        const uint32_t a_raw = load_action(p, a_at);
         t_loaded = p.timestep[min(w0 + wl, N - 1u)];
         if (p.patch) terrain_request(p, lane, tpos);
         // while the loads are in flight: the cell -> player map starts empty, the tile of the single-pass encode zeroed
@@ -1029,7 +1039,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         reset_now = (int64_t)t >= p.horizon;
     }
     // reset (sim.cpp:441-482): rare, and then usually every world of the group at once
-    if (__ballot(active && reset_now) != 0ull) {
+    if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
         if (reset_now) {
             t = 0;
             posori = (private_consts ? (p.starts_w >> (8u * (q & 3u))) & 0xFFu : (uint32_t)s_start[active ? q : 0u]) | (A_NORTH << 8);
@@ -1492,7 +1502,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         tick_pots(p, s_pots, s_obj, nw, lane);
         t += 1;
         const bool reset_now = (int64_t)t >= p.horizon;
-        if (__ballot(active && reset_now) != 0ull) {
+        if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
             if (reset_now) {
                 t = 0;
                 posori = (private_consts ? (p.starts_w >> (8u * (q & 3u))) & 0xFFu : (uint32_t)s_start[active ? q : 0u]) | (A_NORTH << 8);
@@ -1627,7 +1637,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r_pl, (int)(lane * 8u), 0, 0);
         pl_reg[g] = make_uint2(raw[0], raw[1]);
         const size_t a_at = (size_t)(lane < nw * P ? q : 0u) * N + min(w0 + wl, N - 1u);
-        a_raw[g] = p.actions64 ? (uint32_t)p.actions64[a_at] : (uint32_t)p.actions[a_at];
+        a_raw[g] = load_action(p, a_at);
         t_reg[g] = p.timestep[min(w0 + wl, N - 1u)];
     }
     HoldTab hold{};
@@ -1669,7 +1679,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         tick_pots(p, s_pots, s_obj, nw, lane);
         int32_t t = t_reg[g] + 1;
         const bool reset_now = (int64_t)t >= p.horizon;
-        if (__ballot(active && reset_now) != 0ull) {
+        if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
             if (reset_now) {
                 t = 0;
                 posori = ((p.starts_w >> (8u * (q & 3u))) & 0xFFu) | (A_NORTH << 8);

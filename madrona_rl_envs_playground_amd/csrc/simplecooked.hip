@@ -351,10 +351,13 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         uint32_t a_raw;
         if (p.sample)  // uniform over the six actions (include/mrl_envs.h: mrl_rollout_random)
             a_raw = mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, q), 6u);
-        else if (p.actions64)
-            a_raw = (uint32_t)p.actions64[(size_t)q * N + world];
-        else
-            a_raw = (uint32_t)p.actions[(size_t)q * N + world];
+        else {
+            // int32, or int64 narrowed to its low word -- only that word is loaded; one base pointer and a shift rather
+            // than two element loads to choose from (overcooked.hip, load_action)
+            const bool wide = p.actions64 != nullptr;
+            const char *base = wide ? reinterpret_cast<const char *>(p.actions64) : reinterpret_cast<const char *>(p.actions);
+            a_raw = *reinterpret_cast<const uint32_t *>(base + (((size_t)q * N + world) << (wide ? 3 : 2)));
+        }
         clock = p.clock[world];
         static_request();
         // while the loads are in flight: empty cell -> player map, zeroed tile
@@ -411,7 +414,7 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
         t = clock.x + 1;  // sim.cpp:415-420
         reset_now = (int64_t)t >= p.horizon;
     }
-    if (__ballot(active && reset_now) != 0ull) {  // sim.cpp:362-413
+    if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {  // sim.cpp:362-413
         if (reset_now) {
             t = 0;
             dishes_out = 0;
@@ -685,7 +688,7 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
         tick_pots(p, s_pots, s_obj, nw, lane);
         t += 1;
         const bool reset_now = (int64_t)t >= p.horizon;
-        if (__ballot(active && reset_now) != 0ull) {
+        if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
             if (reset_now) {
                 t = 0;
                 dishes_out = 0;

@@ -58,6 +58,11 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         self.action_space = Discrete(NUM_ACTIONS)
         self._player_views = [self.static_world_major_observations[:, i].transpose(1, 2)
                               for i in range(self.num_players)]
+        # On the simulator's own device ``.to(device)`` hands back the very same tensors: what get_obs / n_step return is
+        # then put together once (the per-call host work is what bounds small batches, tools/host_overhead.py)
+        self._resident = env_device == self.static_dones.device
+        self._obs_parts = [(self.static_active_agents[i], self._player_views[i]) for i in range(self.num_players)]
+        self._n_actions = self.static_actions.numel()
         self.n_reset()
 
     def _setup_observation_space(self):
@@ -67,19 +72,22 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         return a.to(self.device)
 
     def get_obs(self):
-        return [VectorObservation(self.to_torch(self.static_active_agents[i]), self.to_torch(self._player_views[i]),
-                                  action_mask=self.static_action_mask)
-                for i in range(self.n_players)]
+        if self._resident:
+            return [VectorObservation(active, view, action_mask=self.static_action_mask) for active, view in self._obs_parts]
+        return [VectorObservation(self.to_torch(active), self.to_torch(view), action_mask=self.static_action_mask) for active, view in self._obs_parts]
 
     def n_step(self, actions):
-        if (actions.dtype == torch.int64 and actions.is_cuda and actions.device == self.static_actions.device and
-                actions.is_contiguous() and actions.numel() == self.static_actions.numel()):
+        # (P, N, 1) int64/int32 on any device -> the simulator's int32 action tensor
+        if (actions.dtype == torch.int64 and actions.device == self.static_actions.device and actions.is_contiguous() and
+                actions.numel() == self._n_actions):
             # what the reference's harness passes (randint_like of a long tensor): the step kernel reads it as it is and
             # mirrors it into static_actions, which the reference fills with a copy kernel of its own (overcooked_env.py:107)
-            self.sim.step_with_actions_i64(actions)
+            self.sim._step_i64_checked(actions.data_ptr())
         else:
             self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
             self.sim.step()
+        if self._resident:
+            return self.get_obs(), self.static_rewards, self.static_dones, self.infos
         return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
 
     def n_reset(self):

@@ -26,6 +26,19 @@ from . import _lib
 from ._lib import MrlError  # noqa: F401  (re-export)
 
 
+
+# The raw handle of torch's current stream on a device.  ``torch.cuda.current_stream(d).cuda_stream`` builds a Stream
+# object on every call (1.1 us measured, a fifth of a step call's host cost -- small batches are bound by that cost,
+# tools/host_overhead.py); torch's own raw getter returns the same pointer as an int.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_ptr(device_index):
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 class ExecMode(enum.Enum):
     CPU = 0
     CUDA = 1
@@ -145,7 +158,7 @@ class _Simulator:
     def step(self):
         """One environment step for all worlds, enqueued on torch's current stream
         (Manager::step; no host synchronisation)."""
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         rc = self._L.mrl_step(self._handle, stream)
         if rc:
             _lib.check(rc)
@@ -167,7 +180,7 @@ class _Simulator:
         """Step reading actions from ``actions`` (int32, the ACTION tensor's shape,
         contiguous, on this GPU) instead of the ACTION tensor."""
         ptr = self._action_pointer(actions)
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         rc = self._L.mrl_step_with_actions(self._handle, ptr, stream)
         if rc:
             _lib.check(rc)
@@ -178,8 +191,12 @@ class _Simulator:
         if (not isinstance(actions, torch.Tensor) or not actions.is_cuda or actions.device.index != self.gpu_id or
                 actions.dtype != torch.int64 or not actions.is_contiguous() or actions.numel() != self._action_numel):
             raise ValueError("actions must be a contiguous int64 tensor of the ACTION tensor's size on the simulator's device")
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
-        rc = self._L.mrl_step_with_actions_i64(self._handle, actions.data_ptr(), stream)
+        self._step_i64_checked(actions.data_ptr())
+
+    def _step_i64_checked(self, ptr):
+        """``mrl_step_with_actions_i64`` on a pointer the caller has already validated (the env wrappers check the
+        harness's tensor once, not twice: every microsecond of host work per call shows at small batches)."""
+        rc = self._L.mrl_step_with_actions_i64(self._handle, ptr, _stream_ptr(self.gpu_id))
         if rc:
             _lib.check(rc)
 
@@ -189,25 +206,25 @@ class _Simulator:
         if not isinstance(actions, torch.Tensor) or actions.dim() < 1:
             raise ValueError("actions must hold K consecutive ACTION tensors")
         ptr = self._action_pointer(actions, steps=int(actions.shape[0]))
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_step_sequence(self._handle, ptr, int(actions.shape[0]), stream))
 
     def rollout_random(self, num_steps, seed=0, first_step=0):
         """``num_steps`` steps under the uniform random policy, actions drawn on the
         device (``mrl_rollout_random``; see ``random_action`` for the stream)."""
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_rollout_random(self._handle, int(num_steps), int(seed) & (2 ** 64 - 1), int(first_step),
                                               stream))
 
     def step_phase1(self, actions=None):
         ptr = self._action_pointer(actions) if actions is not None else None
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_step_phase1(self._handle, ptr, stream))
 
     def step_phase2(self, episode_base=None):
         """``episode_base``: 1-element int32/uint32 CUDA tensor, or None for the
         simulator's own counter."""
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         ptr = episode_base.data_ptr() if episode_base is not None else None
         _lib.check(self._L.mrl_step_phase2(self._handle, ptr, stream))
 
@@ -217,11 +234,11 @@ class _Simulator:
         return bool(self._L.mrl_scan_timed_out(self._handle))
 
     def reseed_shard(self, world_offset, num_worlds_total):
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_reseed_shard(self._handle, int(world_offset), int(num_worlds_total), stream))
 
     def set_episode_counter(self, next_episode):
-        stream = torch.cuda.current_stream(self.gpu_id).cuda_stream
+        stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_set_episode_counter(self._handle, int(next_episode), stream))
 
     @property
