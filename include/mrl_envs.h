@@ -246,13 +246,14 @@ int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 
 /* One environment step for every world: replaces Manager::step.
  * Hanabi, Cartpole and the balance beam number new episodes in ascending world order, which
- * takes a prefix sum over the worlds that finished.  By default mrl_step is two launches
- * (phase 1, phase 2: the kernel boundary is the grid-wide hand-off, nothing waits inside a
- * kernel).  Two kinds of launch DO wait for other workgroups inside the kernel: the
- * single-launch step behind mrl_debug_set("fused_step") -- each workgroup takes a ticket (one
- * atomic increment) as its index and waits only for lower tickets, i.e. workgroups known to
- * have started (csrc/episode_scan.hpp; measured slower than two launches, the tickets
- * serialise) -- and the persistent multi-step launches of mrl_rollout_random, which need all
+ * takes a prefix sum over the worlds that finished.  For all but small batches mrl_step is two
+ * launches (phase 1, phase 2: the kernel boundary is the grid-wide hand-off, nothing waits inside
+ * a kernel).  Two kinds of launch DO wait for other workgroups inside the kernel: the
+ * single-launch step -- each workgroup takes a ticket (one atomic increment) as its index and
+ * waits only for lower tickets, i.e. workgroups known to have started (csrc/episode_scan.hpp);
+ * the tickets serialise, so it is the default only where the host's launch rate is the bound
+ * (Cartpole up to 1024 worlds, Hanabi up to 10000; mrl_debug_set("fused_step") 1 / 2 forces one /
+ * two launches) -- and the persistent multi-step launches of mrl_rollout_random, which need all
  * their workgroups resident and are therefore launched cooperatively.  Every such wait is
  * bounded; if one ever expired the SCAN_TIMEOUT tensor of the game becomes nonzero, the
  * episode numbers from that step on are unspecified, and every later mrl_step* /

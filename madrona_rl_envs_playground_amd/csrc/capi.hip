@@ -31,8 +31,8 @@ static const char *const kDebugKeys[] = {
     "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
-    "fused_step",            // 1: mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel ticketed prefix (episode_scan.hpp)
-                             // instead of the default phase 1 + phase 2 launches (measured slower)
+    "fused_step",            // mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel ticketed prefix (episode_scan.hpp) or as
+                             // phase 1 + phase 2 launches: 0 by batch size (one launch for small batches), 1 always one, 2 always two
     "inject_scan_timeout",   // 1: the simulator's SCAN_TIMEOUT alarm is raised right after construction (tests of the error path)
     "ablate",                // diagnostic build only: phase ablation mask
     "stamps",                // diagnostic build only: in-kernel time stamps

@@ -25,6 +25,10 @@
 namespace {
 
 constexpr int kBlock = 256;
+// mrl_step as ONE launch (ticketed in-kernel prefix) up to this many worlds, as two launches above: a small batch is bound
+// by the host's launch rate (~4.5 us per launch), a large one by the tickets' serialisation (tools/fused_crossover.py, us per
+// step one / two launches: 32 worlds 4.2 / 7.1, 1000 6.8 / 7.0, 10000 8.1 / 5.8, 1 M 28.5 / 14.3)
+constexpr uint32_t kFusedStepMaxWorlds = 1024;
 
 #define GRAVITY 9.8
 #define MASSCART 1.0
@@ -596,7 +600,11 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             }
         }
         sim->alarm.init(sim->arena);
-        sim->fused_step = mrl::debug_get("fused_step", 0) != 0;
+        {
+            // mrl_debug_set fused_step: 0 = by batch size, 1 = always one launch, 2 = always two
+            const int64_t knob = mrl::debug_get("fused_step", 0);
+            sim->fused_step = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
+        }
         sim->ticket = sim->arena.alloc<uint32_t>(1);
         if (sim->fused_grid) {
             int per_cu = 0, cus = 0;

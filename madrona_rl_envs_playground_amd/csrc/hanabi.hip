@@ -48,6 +48,10 @@ constexpr int kWave = 64;
 #endif
 constexpr int kWavesPerBlock = MRL_HANABI_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
+// mrl_step as ONE launch (ticketed in-kernel prefix) up to this many worlds, as two launches above: a small batch is bound
+// by the host's launch rate (~4.5 us per launch), a large one by the tickets' serialisation (tools/fused_crossover.py, us per
+// step one / two launches: 32 worlds 15.1 / 15.8, 1000 18.7 / 19.7, 10000 18.7 / 20.0, 16384 20.5 / 20.4, 65536 29.2 / 26.6)
+constexpr uint32_t kFusedStepMaxWorlds = 10000;
 constexpr int kWorldsPerWave = MRL_HANABI_WPW;
 constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
 #ifndef MRL_HANABI_EU
@@ -1717,7 +1721,11 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->alarm.init(sim->arena);
         sim->ticket = sim->arena.alloc<uint32_t>(1);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
-        sim->fused = mrl::debug_get("fused_step", 0) != 0;  // default: two launches, the kernel boundary is the grid-wide hand-off
+        {
+            // mrl_debug_set fused_step: 0 = by batch size, 1 = always one launch, 2 = always two
+            const int64_t knob = mrl::debug_get("fused_step", 0);
+            sim->fused = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
+        }
         {
             // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each
             // other: only usable when the grid fits the GPU in one go and each workgroup owns one sub-block

@@ -118,7 +118,8 @@ def test_two_phase_equals_single_call(n, steps, hip_lib):
     from madrona_rl_envs_playground_amd._lib import debug_knobs
     with debug_knobs({"fused_step": 1}):
         s1 = make(n)
-    s2 = make(n)
+    with debug_knobs({"fused_step": 2}):  # (0 = the library's choice by batch size: one launch up to 1024 worlds)
+        s2 = make(n)
     assert s1.kernel_name == "mrl_cartpole_step_fused" and s2.kernel_name == "mrl_cartpole_step"
     torch.manual_seed(1)
     for _ in range(steps):

@@ -145,7 +145,8 @@ def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
     counts inside the kernel); the two-phase calls are two launches.  Same tensors either way."""
     with debug_knobs({"fused_step": 1}):
         s1 = make(cfg, n)
-    s2 = make(cfg, n)
+    with debug_knobs({"fused_step": 2}):  # (0 = the library's choice by batch size: one launch up to 10000 worlds)
+        s2 = make(cfg, n)
     assert s1.kernel_name == "mrl_hanabi_step_fused" and s2.kernel_name == "mrl_hanabi_step"
     gen = torch.Generator(device="cuda").manual_seed(11)
     mask = s1.action_mask_tensor().to_torch()
@@ -173,7 +174,7 @@ def test_device_random_policy(fused, hip_lib, oracle_lib):
     moves, include/mrl_envs.h): checked step by step, then a multi-step call against a replay."""
     from madrona_rl_envs_playground_amd.simulators import random_hanabi_action
     n, seed = 2500, 0xC0FFEE1234
-    with debug_knobs({"fused_step": 1} if fused else {}):
+    with debug_knobs({"fused_step": 1 if fused else 2}):
         sim, twin = make(FULL, n), make(FULL, n)
     orc = oracle_lib.HanabiOracle(FULL, n, num_threads=8)
     world = np.arange(n)
