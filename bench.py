@@ -289,6 +289,25 @@ def run(args):
         del seq_actions
 
     if single:
+        # the headline loop once more as a captured HIP graph (the C ABI only enqueues on the caller's stream, so a step
+        # call can be captured like any other stream work): the same launches, one per step, without the host's per-call
+        # work -- what is left is the GPU's own time per step
+        per_graph = 200
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(per_graph):
+                    sim.step_with_actions(pool[i % args.pool])
+        graph.replay()
+        us = launches_us(lambda i: graph.replay(), 10) / per_graph
+        extras["graph_replay"] = {
+            "value": n / (us * 1e-6), "unit": "env-steps/s", "us_per_step": us, "steps_per_graph": per_graph,
+            "frac": sim.bytes_per_world_step * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "note": "the headline's launches (one mrl_step_with_actions per step) captured once with torch.cuda.graph and replayed"}
+        del graph
+
+    if single:
         # the reference's own timed regions, on this engine's drop-in wrappers
         from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
         env = OvercookedMadrona(args.layout, n, local_rank, horizon=args.horizon)

@@ -146,6 +146,34 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
     generic.close()
 
 
+def test_steps_captured_in_a_hip_graph_equal_eager_steps(hip_lib):
+    """The C ABI only enqueues on the caller's stream (no host synchronisation, no allocation): step calls can be
+    captured with torch.cuda.graph like any other stream work and replayed (bench.py's `graph_replay` leg).
+    A replayed graph of 12 steps leaves the same tensors as the same 12 calls issued one by one."""
+    params = layouts.get_base_layout_params("cramped_room", 37)
+    n, P = 33000, 2
+    eager, captured = make_sim(params, n), make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    acts = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(12)]
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for a in acts:
+                captured.step_with_actions(a)
+    for rep in range(4):  # 48 steps: across a horizon reset
+        graph.replay()
+        for a in acts:
+            eager.step_with_actions(a)
+        torch.cuda.synchronize()
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(eager, get)().to_torch(), getattr(captured, get)().to_torch()), f"{get}, replay {rep}"
+    eager.close()
+    captured.close()
+
+
 @pytest.mark.parametrize("layout,cap,n", [("cramped_room", None, 4099), ("counter_circuit", None, 1001), ("asymmetric_advantages", None, 515),
                                           ("multiplayer_schelling", None, 130), ("cramped_room", None, 7)])
 def test_direct_patch_equals_searched(layout, cap, n, hip_lib):
