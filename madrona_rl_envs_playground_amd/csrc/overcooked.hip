@@ -644,7 +644,17 @@ __device__ __forceinline__ void patch_direct(const StepParams &p, const uint32_t
         const uint32_t e = hold.e[k];
         const uint32_t i = (e >> 16) & 0x3FFFu;
         const bool holder = ((e >> 30) & 1u) != 0u && i < ncells;
-        const uint32_t o = s_obj[holder ? i : 0u];
+        uint32_t o = s_obj[holder ? i : 0u];
+        if (!kUndo && holder && (e >> 31)) {
+            // the pot's tick (sim.cpp:430-438) rides on this read instead of a pass of its own (tick_pots) with its own LDS
+            // round trip in front of the first store: every pot that can hold a soup is a holder cell; a pot of a world
+            // that reset in this step has been emptied by now and does not tick, like an empty one
+            const int32_t tick = (int8_t)(o >> 24);
+            if ((o & 0xFFu) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o))) {
+                o = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+                const_cast<uint32_t *>(s_obj)[i] = o;
+            }
+        }
         const bool player = k == 0 && active;
         if (player || (holder && (o & 0xFFu) != O_NONE)) {
             const uint32_t l = player ? wl : __umulhi(i, p.inv_c);
@@ -1032,7 +1042,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     if (!kInit) {
         if (!ABLATED(4)) {
             transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
-            tick_pots(p, s_pots, s_obj, nw, lane);
+            if (!p.direct) tick_pots(p, s_pots, s_obj, nw, lane);  // direct: the holder lanes of the encode tick the pots
         }
         // horizon (sim.cpp:485-489)
         t = t_loaded + 1;
@@ -1499,7 +1509,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         const uint32_t old_cell = wl * C + (posori & 0xFFu);
         int32_t reward_world = 0;
         transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, a, posori, held, reward_world);
-        tick_pots(p, s_pots, s_obj, nw, lane);
+        if (!p.direct) tick_pots(p, s_pots, s_obj, nw, lane);  // direct: the holder lanes of the encode tick the pots
         t += 1;
         const bool reset_now = (int64_t)t >= p.horizon;
         if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
@@ -1676,7 +1686,7 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         if (g == 0) STAMP(1);
         int32_t reward_world = 0;
         transition_lanes<kP>(p, s_terrain, s_obj + wl * C, s_x, s_sum, s_blk, P, lane, active, wl, q, act, posori, held, reward_world);
-        tick_pots(p, s_pots, s_obj, nw, lane);
+        if (!p.direct) tick_pots(p, s_pots, s_obj, nw, lane);  // direct: the holder lanes of the encode tick the pots
         int32_t t = t_reg[g] + 1;
         const bool reset_now = (int64_t)t >= p.horizon;
         if (__builtin_expect(__ballot(active && reset_now) != 0ull, 0)) {
