@@ -410,7 +410,7 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
     if (!kInit) {
         dishes_out = clock.y;
         transition<kP>(p, s_terrain, s_pots, s_obj, active, wl, q, act, posori, held, dishes_out, reward_world);
-        tick_pots(p, s_pots, s_obj, nw, lane);
+        if (!direct) tick_pots(p, s_pots, s_obj, nw, lane);  // direct: the holder lanes of the encode tick the pots
         t = clock.x + 1;  // sim.cpp:415-420
         reset_now = (int64_t)t >= p.horizon;
     }
@@ -447,7 +447,16 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
                 const uint32_t e = hold[k];
                 const uint32_t i = (e >> 16) & 0x3FFFu;
                 const bool holder = ((e >> 30) & 1u) != 0u && i < ncells;
-                const uint32_t o = s_obj[holder ? i : 0u];
+                uint32_t o = s_obj[holder ? i : 0u];
+                if (holder && (e >> 31)) {
+                    // the pot's tick (sim.cpp:350-360) rides on this read instead of tick_pots' own LDS round trip: every pot
+                    // that can hold a soup is a holder cell; a pot emptied by this step's reset does not tick, like an empty one
+                    const int32_t tick = (int8_t)(o >> 24);
+                    if ((o & 0xFFu) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o))) {
+                        o = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
+                        s_obj[i] = o;
+                    }
+                }
                 const bool player = k == 0 && active;
                 if (player || (holder && (o & 0xFFu) != O_NONE)) {
                     const Tail10 t10 = cell_tail(player ? (uint32_t)T_AIR : ((e >> 31) ? (uint32_t)T_POT : (uint32_t)T_COUNTER),
