@@ -631,7 +631,7 @@ __device__ __forceinline__ void hold_request(const StepParams &p, uint32_t lane,
 }
 // kUndo: put the same rows back to their static content (after the stream-out of a tile that outlives the step)
 template <int kP, bool kUndo>
-__device__ __forceinline__ void patch_direct(const StepParams &p, const uint32_t *s_obj, const uint8_t *s_flags, const HoldTab &hold,
+__device__ __forceinline__ void patch_direct(const StepParams &p, uint32_t *s_obj, const uint8_t *s_flags, const HoldTab &hold,
                                              uint8_t *tile, uint32_t P, uint32_t nw, bool active, uint32_t wl, uint32_t q, uint32_t posori,
                                              uint32_t held)
 {
@@ -652,7 +652,7 @@ __device__ __forceinline__ void patch_direct(const StepParams &p, const uint32_t
             const int32_t tick = (int8_t)(o >> 24);
             if ((o & 0xFFu) == O_SOUP && tick >= 0 && tick < (int32_t)lookup16(p.times_w, recipe_of(o))) {
                 o = (o & 0x00FFFFFFu) | ((uint32_t)(uint8_t)(tick + 1) << 24);
-                const_cast<uint32_t *>(s_obj)[i] = o;
+                s_obj[i] = o;
             }
         }
         const bool player = k == 0 && active;
@@ -683,7 +683,7 @@ __device__ __forceinline__ void patch_direct(const StepParams &p, const uint32_t
 // put back to their static content, so the next step again only touches what is dynamic then; s_prev remembers
 // each world's urgency flag as the tile has it.
 template <int kP, bool kRestore>
-__device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
+__device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags, uint8_t *s_prev,
                                               const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t l0,
                                               uint32_t nl, uint32_t lane, const HoldTab &hold, bool active, uint32_t wl, uint32_t q,
@@ -2180,15 +2180,23 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             sim->groups_name = "mrl_overcooked_step_groups_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false, 2>"; \
         }                                                                                                           \
     }
-            // Groups of worlds a wave steps one after the other in the single step (mrl_overcooked_step_groups_fixed).
-            // Measured on MI355X, us per launch with one / two groups per wave: cramped_room 32768 worlds (4096 groups)
-            // 8.26 / 9.34, 65536 14.7 / 14.4, 131072 26.8 / 24.9, 524288 118 / 111, 1 M 228 / 240; at 8192 groups
-            // counter_circuit 14.3 / 14.2, asymmetric_advantages 17.8 / 18.1, coordination_ring 11.0 / 11.3; counter_circuit
-            // 131072 worlds (32768 groups) 54.4 / 49.2.  So: two groups from 12288 to 65536 groups.
+            // Groups of worlds a wave steps one after the other in the single step (mrl_overcooked_step_groups_fixed): two
+            // as soon as the launch has more groups than waves fit the GPU at once (then a second generation of waves
+            // would start behind the first anyway, and a wave that requests both groups' state up front and steps the second
+            // while the first one's stores drain does better); one below that, where two would halve the waves in flight.
+            // Measured on MI355X with the r02_e kernels, us per launch one / two groups per wave -- cramped_room (4096 waves
+            // fit): 32768 worlds 7.99 / 8.14, 36864 10.27 / 10.12, 45056 11.2 / 10.8, 65536 14.1 / 13.1, 131072 25.7 / 24.1,
+            // 262144 54.8 / 48.6, 524288 120 / 112, 1 M 239 / 240; at 32768 worlds (8192 groups) asymmetric_advantages (3072
+            // fit) 16.7 / 15.7, counter_circuit (3072) 13.7 / 13.1, coordination_ring (6144) 10.49 / 10.48, forced_coordination
+            // 10.60 / 10.68; coordination_ring 16640 worlds (4160 groups) 6.4 / 7.7.
             // mrl_debug_set overcooked.groups: 0 = that rule, 1 = always one, 2 = always two.
             const int64_t groups_knob = mrl::debug_get("overcooked.groups", 0);
             const uint64_t ngroups = ((uint64_t)N + wpw - 1) / wpw;
-            const int64_t groups = groups_knob ? groups_knob : ((ngroups >= 12288 && ngroups <= 65536) ? 2 : 1);
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id);
+            const uint64_t wg_per_cu = std::min<uint64_t>(8, std::max<uint64_t>(1, (160u * 1024u) / std::max<uint32_t>(sim->lds_bytes, 1u)));
+            const uint64_t waves_at_once = (uint64_t)cus * wg_per_cu * kWavesPerBlock;
+            const int64_t groups = groups_knob ? groups_knob : (ngroups > waves_at_once + waves_at_once / 8 ? 2 : 1);
             // the five standard layouts: cells, worlds per wave, grid width, pots
             // the five standard layouts: cells, worlds per wave, grid width, pots, holder cells
             MRL_FIXED(20, 8, 5, 1, 6)    // cramped_room
