@@ -1123,14 +1123,23 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
 // instructions per wave, PMC), so fewer, fuller waves win until latency is no longer hidden.
 // (With 16 worlds per wave the kernel must be held to 128 VGPRs: at the 132 the compiler picks
 // unasked, a quarter of the workgroups start only when the first ones finish.)
+// The leading scalar arguments -- what a wave needs to find its worlds and request their records and actions -- are
+// preloaded into SGPRs by the command processor (-amdgpu-kernarg-preload-count in the Makefile; a by-value struct is not
+// eligible): the record loads do not wait for a scalar load of the argument segment.  The struct carries the rest.
 template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU))) mrl_hanabi_step(const HanabiParams p)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
+mrl_hanabi_step(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t hot_chunk, const HanabiParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
+    HanabiParams q = p;
+    q.records = hot_records;
+    q.actions = hot_actions;
+    q.num_worlds = hot_num_worlds;
+    q.chunk = hot_chunk;
     bool last_over;
-    const uint32_t total = step_body<kV, false>(p, smem, s_counts, &last_over, FusedScan{}, blockIdx.x);
-    if (threadIdx.x == 0) p.block_counts[blockIdx.x] = total;
+    const uint32_t total = step_body<kV, false>(q, smem, s_counts, &last_over, FusedScan{}, blockIdx.x);
+    if (threadIdx.x == 0) q.block_counts[blockIdx.x] = total;
 }
 
 
@@ -1542,9 +1551,9 @@ struct HanabiSim final : mrl_sim {
         HanabiParams a = params;
         a.actions = actions ? actions : action;
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step<2>), dim3(grid), dim3(kBlock), 0, stream, a); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step<1>), dim3(grid), dim3(kBlock), 0, stream, a); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step<0>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step<2>), dim3(grid), dim3(kBlock), 0, stream, a.records, a.actions, a.num_worlds, a.chunk, a); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step<1>), dim3(grid), dim3(kBlock), 0, stream, a.records, a.actions, a.num_worlds, a.chunk, a); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step<0>), dim3(grid), dim3(kBlock), 0, stream, a.records, a.actions, a.num_worlds, a.chunk, a); break;
         }
         MRL_HIP(hipGetLastError());
     }
