@@ -23,6 +23,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size
     "overcooked.no_direct",  // 1: the single-pass encode looks for its dynamic cells (cell -> player map + ballot compaction) instead of
                              // taking them from the player lanes and the holder-cell table
+    "overcooked.whole_store",   // single-pass stream-out stores: 0 by slab size and group alignment (default), 1 write-through, 2 plain
     "overcooked.store_policy",  // multi-pass stream-out stores: 0 by slab size (default), 1 sc1 write-through, 2 plain, 3 nt
     "overcooked.wide_rollout",  // 1: the multi-step launches keep the single step's group size (default: twice as wide where it fits)
     "overcooked.groups",     // groups of worlds a wave steps one after the other in the single step of the standard layouts: 0 by batch size, 1, 2

@@ -482,6 +482,13 @@ __device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_
 }
 // Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
+// kPlain: ordinary stores instead of write-through ones.  Write-through wins while the slab fits the 256 MiB Infinity Cache
+// and whenever a group's slab is whole 128-byte lines (cramped_room, counter_circuit); a group slab that is NOT (1300- or
+// 2340-byte worlds) ends in a line it shares with the next group's wave, and two write-through partial lines that must go out
+// to HBM cost a read-modify-write each: coordination_ring at 262144 worlds 121 us per step write-through, 71 us plain
+// (1 M worlds 534 / 305; asymmetric_advantages 210 / 133 and 894 / 570) -- the L2 merges the halves before it writes back.
+// The host picks the instantiation (overcooked.whole_store: 0 by slab size and alignment, 1 write-through, 2 plain).
+template <bool kPlain = false>
 __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset, const uint4 &v)
 {
     u32x4 r;
@@ -492,10 +499,11 @@ __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, u
 #ifndef MRL_WHOLE_STORE_AUX
 #define MRL_WHOLE_STORE_AUX 16
 #endif
-    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, MRL_WHOLE_STORE_AUX);  // aux bit 4 = sc1 (write-through)
+    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, kPlain ? 0 : MRL_WHOLE_STORE_AUX);  // aux bit 4 = sc1 (write-through)
 }
 
 // Single-pass encode of a group's observation slab (small layouts; see the call site).
+template <bool kPlain = false>
 __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t *s_terrain, const uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags,
                                               uint8_t *s_tile, uint32_t P, uint32_t w0, uint32_t nw, uint32_t lane,
@@ -559,12 +567,12 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
         const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
         const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
-        stream_store_rsrc(out, ka << 4, va);
-        stream_store_rsrc(out, kb << 4, vb);
-        stream_store_rsrc(out, kc << 4, vc);
-        stream_store_rsrc(out, kd << 4, vd);
+        stream_store_rsrc<kPlain>(out, ka << 4, va);
+        stream_store_rsrc<kPlain>(out, kb << 4, vb);
+        stream_store_rsrc<kPlain>(out, kc << 4, vc);
+        stream_store_rsrc<kPlain>(out, kd << 4, vd);
     }
-    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc(out, k0 << 4, src[k0]);
+    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc<kPlain>(out, k0 << 4, src[k0]);
     const uint32_t done_bytes = head + (body << 4);
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
 }
@@ -682,7 +690,7 @@ __device__ __forceinline__ void patch_direct(const StepParams &p, uint32_t *s_ob
 // kRestore (persistent rollouts, where the tile outlives the step): after the stream-out the patched rows are
 // put back to their static content, so the next step again only touches what is dynamic then; s_prev remembers
 // each world's urgency flag as the tile has it.
-template <int kP, bool kRestore>
+template <int kP, bool kRestore, bool kPlain = false>
 __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t *s_terrain, uint32_t *s_obj,
                                               const uint32_t *s_pl, const uint8_t *s_cur, const uint8_t *s_flags, uint8_t *s_prev,
                                               const uint16_t *s_list, uint32_t ndyn, uint8_t *tile, uint32_t P, uint32_t w0, uint32_t l0,
@@ -758,12 +766,12 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
         const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
         const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
-        stream_store_rsrc(out, ka << 4, va);
-        stream_store_rsrc(out, kb << 4, vb);
-        stream_store_rsrc(out, kc << 4, vc);
-        stream_store_rsrc(out, kd << 4, vd);
+        stream_store_rsrc<kPlain>(out, ka << 4, va);
+        stream_store_rsrc<kPlain>(out, kb << 4, vb);
+        stream_store_rsrc<kPlain>(out, kc << 4, vc);
+        stream_store_rsrc<kPlain>(out, kd << 4, vd);
     }
-    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc(out, k0 << 4, src[k0]);
+    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc<kPlain>(out, k0 << 4, src[k0]);
     const uint32_t done_bytes = body << 4;
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = reinterpret_cast<const uint8_t *>(src)[done_bytes + lane];
     if constexpr (kRestore) {
@@ -901,7 +909,7 @@ __device__ __forceinline__ uint32_t load_action(const StepParams &p, size_t at)
     return *reinterpret_cast<const uint32_t *>(base + (at << (wide ? 3 : 2)));
 }
 
-template <bool kInit, int kP>
+template <bool kInit, int kP, bool kPlain = false>
 __device__ __forceinline__ void step_body(const StepParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1116,11 +1124,11 @@ __device__ __forceinline__ void step_body(const StepParams &p)
             // patched, measured slower: 8.6 vs 8.25 us.)
             const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
             STAMP(4);
-            observe_patch<kP, false>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
+            observe_patch<kP, false, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
                                      wl, q, posori, held);
             STAMP(5);
         } else
-            observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
+            observe_whole<kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane, true);
         store_state();
         STAMP(15);
         STAMP_REALTIME(14);
@@ -1283,10 +1291,10 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     STAMP_REALTIME(14);
 }
 
-template <bool kInit, int kP>
+template <bool kInit, int kP, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
 {
-    step_body<kInit, kP>(p);
+    step_body<kInit, kP, kPlain>(p);
 }
 
 // Per-wave LDS offsets of the single-pass, two-player, private-constants configuration: the same formulas as
@@ -1387,12 +1395,12 @@ __device__ __forceinline__ void take_hot_args(StepParams &q, MRL_HOT_ARGS)
 }
 #define MRL_HOT_PASS hot_cell_obj, hot_players, hot_timestep, hot_actions, hot_consts, hot_terr_off, hot_num_worlds, hot_per_xcd
 
-template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64 = false>
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64 = false, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(MRL_HOT_ARGS, const StepParams p)
 {
     StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
     take_hot_args<kI64>(q, MRL_HOT_PASS);
-    step_body<false, 2>(q);
+    step_body<false, 2, kPlain>(q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1412,7 +1420,7 @@ __host__ __device__ __forceinline__ uint32_t mrl_random_action(uint64_t seed, ui
     return mrl::scale(mrl::policy_hash(seed, step, world, player), 6u);  // uniform over the six actions
 }
 
-template <int kP>
+template <int kP, bool kPlain = false>
 __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
                                              int32_t *action_out, const int32_t *action_seq)
 {
@@ -1538,10 +1546,10 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         if (p.patch) {
             // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
             const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
-            observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active, wl,
-                                    q, posori, held);
+            observe_patch<kP, true, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
+                                             wl, q, posori, held);
         } else {
-            observe_whole(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+            observe_whole<kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
         if (active) {  // after the stream-out, like the state stores of the single step
             p.reward[(size_t)q * N + world] = reward_world;
@@ -1558,16 +1566,16 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
     }
 }
 
-template <int kP>
+template <int kP, bool kPlain = false>
 __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout(const StepParams p, uint32_t num_steps, uint64_t seed,
                                                                                  uint32_t first_step, int32_t *action_out,
                                                                                  const int32_t *action_seq)
 {
-    rollout_body<kP>(p, num_steps, seed, first_step, action_out, action_seq);
+    rollout_body<kP, kPlain>(p, num_steps, seed, first_step, action_out, action_seq);
 }
 
 // the multi-step launches for one layout size known at compile time (see mrl_overcooked_step_fixed)
-template <int kC, int kW, int kWidth, int kPots, int kHold>
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kPlain = false>
 __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout_fixed(const StepParams p, uint32_t num_steps, uint64_t seed,
                                                                                        uint32_t first_step, int32_t *action_out,
                                                                                        const int32_t *action_seq)
@@ -1576,7 +1584,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
     // with the tile and the cell -> player map alive across steps the search costs a multi-step launch little: the table
     // only where it is one round (measured, cramped_room 16 worlds per wave: 4.46 us per step searched, 4.72 with two rounds)
     q.direct = fixed_hold_entries(kW, kHold) <= 64u ? 1u : 0u;
-    rollout_body<2>(q, num_steps, seed, first_step, action_out, action_seq);
+    rollout_body<2, kPlain>(q, num_steps, seed, first_step, action_out, action_seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1589,7 +1597,7 @@ __global__ void __launch_bounds__(kWavesPerBlock * kWave) mrl_overcooked_rollout
 // launches -- and with half as many waves per SIMD a wave's phases take half as long, so the first stores leave
 // earlier.  Same state and output arrays, same results.
 // ---------------------------------------------------------------------------------------------
-template <int kP, int kG>
+template <int kP, int kG, bool kPlain = false>
 __device__ __forceinline__ void groups_body(const StepParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1713,8 +1721,8 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
         if (g == 0) STAMP(3);
         const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
         if (g == 0) STAMP(4);
-        observe_patch<kP, true>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active, wl, q,
-                                posori, held);
+        observe_patch<kP, true, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active, wl,
+                                        q, posori, held);
         if (g == 0) STAMP(5);
         // the group's state, rewards and flags: behind its stream-out, like the ordinary step
         uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
@@ -1735,12 +1743,12 @@ __device__ __forceinline__ void groups_body(const StepParams &p)
     STAMP_REALTIME(14);
 }
 
-template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64, int kG>
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kI64, int kG, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step_groups_fixed(MRL_HOT_ARGS, const StepParams p)
 {
     StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
     take_hot_args<kI64>(q, MRL_HOT_PASS);
-    groups_body<2, kG>(q);
+    groups_body<2, kG, kPlain>(q);
 }
 
 // fallback for layouts without the single-pass encode: draw into the ACTION tensor, then an ordinary step
@@ -1770,6 +1778,10 @@ struct OvercookedSim final : mrl_sim {
     uint32_t H = 0;
     uint32_t grid = 0, lds_bytes = 0;
     bool generic = false;  // tests: two-player layouts through the any-player-count transition as well
+    using StepKernel = void (*)(const StepParams);
+    using RolloutKernel = void (*)(const StepParams, uint32_t, uint64_t, uint32_t, int32_t *, const int32_t *);
+    StepKernel generic_step = nullptr;        // mrl_overcooked_step<false, 2 or 0, store flavour>
+    RolloutKernel generic_rollout = nullptr;  // mrl_overcooked_rollout<2 or 0, store flavour>
     using FixedKernel = void (*)(MRL_HOT_ARGS, const StepParams);
     FixedKernel fixed_kernel = nullptr;  // mrl_overcooked_step_fixed<...> when the parameters are exactly its
     FixedKernel fixed_kernel_i64 = nullptr;
@@ -1802,10 +1814,8 @@ struct OvercookedSim final : mrl_sim {
         else if (fixed_kernel)
             hipLaunchKernelGGL(a.actions64 ? fixed_kernel_i64 : fixed_kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, a.cell_obj, a.players,
                                a.timestep, hot_actions, a.consts, a.terr_off, a.num_worlds, a.per_xcd, a);
-        else if (a.P == 2 && !generic)
-            hipLaunchKernelGGL((mrl_overcooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else
-            hipLaunchKernelGGL((mrl_overcooked_step<false, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL(generic_step, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         MRL_HIP(hipGetLastError());
     }
 
@@ -1831,12 +1841,9 @@ struct OvercookedSim final : mrl_sim {
             else if (fixed_rollout)
                 hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, seed,
                                    first_step, action, (const int32_t *)nullptr);
-            else if (params.P == 2 && !generic)
-                hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
             else
-                hipLaunchKernelGGL((mrl_overcooked_rollout<0>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, seed, first_step, action, (const int32_t *)nullptr);
+                hipLaunchKernelGGL(generic_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, seed,
+                                   first_step, action, (const int32_t *)nullptr);
             MRL_HIP(hipGetLastError());
             return;
         }
@@ -1858,12 +1865,9 @@ struct OvercookedSim final : mrl_sim {
             else if (fixed_rollout)
                 hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, 0ull, 0u,
                                    action, actions);
-            else if (params.P == 2 && !generic)
-                hipLaunchKernelGGL((mrl_overcooked_rollout<2>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, 0ull, 0u, action, actions);
             else
-                hipLaunchKernelGGL((mrl_overcooked_rollout<0>), dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream,
-                                   params, num_steps, 0ull, 0u, action, actions);
+                hipLaunchKernelGGL(generic_rollout, dim3(grid), dim3(kWavesPerBlock * kWave), lds_bytes, stream, params, num_steps, 0ull, 0u,
+                                   action, actions);
             MRL_HIP(hipGetLastError());
             return;
         }
@@ -2141,17 +2145,27 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
                            ? 1u
                            : 0u;
         }
+        // Stores of the single-pass stream-out (stream_store_rsrc): write-through, except where the slab is larger than the
+        // Infinity Cache AND a group's slab is not whole 128-byte lines -- then ordinary stores, which the L2 merges
+        const auto plain_for = [&](uint32_t group_worlds) {
+            const int64_t knob = mrl::debug_get("overcooked.whole_store", 0);  // 0 by slab size and alignment, 1 write-through, 2 plain
+            const uint64_t slab = (uint64_t)N * a.block_bytes;
+            return knob ? knob == 2 : (slab > (256ull << 20) && ((uint64_t)group_worlds * a.block_bytes) % 128u != 0);
+        };
+        const bool plain = plain_for(wpw);
+        {
+            const bool pairs = a.P == 2 && !sim->generic;  // two-player layouts (all five standard ones) exchange through DPP instead of LDS
+            sim->generic_step = pairs ? (plain ? &mrl_overcooked_step<false, 2, true> : &mrl_overcooked_step<false, 2, false>)
+                                      : (plain ? &mrl_overcooked_step<false, 0, true> : &mrl_overcooked_step<false, 0, false>);
+            sim->generic_rollout = pairs ? (plain ? &mrl_overcooked_rollout<2, true> : &mrl_overcooked_rollout<2, false>)
+                                         : (plain ? &mrl_overcooked_rollout<0, true> : &mrl_overcooked_rollout<0, false>);
+        }
         if (sim->lds_bytes > 65536) {
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<false, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_rollout<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
-            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_rollout<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sim->generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sim->lds_bytes));
+            MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sim->generic_rollout), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sim->lds_bytes));
         }
         // Few worlds of a large layout leave most of the GPU idle at one wave per world: the four waves of a
         // workgroup then share a world.  Measured on many_player_layout (15x17) at 1000 worlds, us per step
@@ -2168,15 +2182,20 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
                        a.off_cur == f.off_cur && a.off_flags == f.off_flags && a.off_terr == f.off_terr && a.off_list == f.off_list &&
                        a.off_tile == f.off_tile && a.lds_wave_stride == f.stride && !mrl::debug_get("overcooked.no_fixed", 0);
             };
-#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_, HOLD_)                                                                          \
-    if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_, HOLD_)) {                                                   \
-        sim->fixed_kernel = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                    \
-        sim->fixed_kernel_i64 = &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>;                          \
-        sim->fixed_rollout = &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                \
+#define MRL_FIXED(C_, WPW_, WIDTH_, POTS_, HOLD_)                                                                    \
+    if (!sim->fixed_kernel && matches(C_, WPW_, WIDTH_, POTS_, HOLD_)) {                                            \
+        sim->fixed_kernel = plain ? &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, true>         \
+                                  : &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, false>;       \
+        sim->fixed_kernel_i64 = plain ? &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, true>      \
+                                      : &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, false>;    \
+        sim->fixed_rollout = plain ? &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>            \
+                                   : &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false>;          \
         sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false>";      \
         if (groups == 2) {                                                                                          \
-            sim->groups_kernel = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, 2>;              \
-            sim->groups_kernel_i64 = &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, 2>;           \
+            sim->groups_kernel = plain ? &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, 2, true>     \
+                                       : &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, 2, false>;   \
+            sim->groups_kernel_i64 = plain ? &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, 2, true>  \
+                                           : &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, 2, false>; \
             sim->groups_name = "mrl_overcooked_step_groups_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false, 2>"; \
         }                                                                                                           \
     }
@@ -2256,7 +2275,8 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             uint32_t stride = 0;
 #define MRL_WIDE(C_, W2_, WIDTH_, POTS_, HOLD_)                                                                             \
     if (!sim->wide_rollout && a.C == C_ && rw == W2_ && a.W == WIDTH_ && a.num_pots == POTS_ && holders.size() == HOLD_) {                      \
-        sim->wide_rollout = &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_>;                                  \
+        sim->wide_rollout = plain_for(rw) ? &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, true>             \
+                                          : &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, false>;           \
         stride = fixed_layout(C_, W2_).stride;                                                                      \
     }
             MRL_WIDE(20, 16, 5, 1, 6)  // cramped_room

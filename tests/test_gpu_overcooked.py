@@ -146,6 +146,39 @@ def test_generic_kernel_equals_specialised(layout, n, wpw, hip_lib):
     generic.close()
 
 
+@pytest.mark.parametrize("layout,n,knobs", [("coordination_ring", 4099, {"overcooked.wpw": 4}), ("asymmetric_advantages", 16391, {"overcooked.wpw": 4}),
+                                            ("coordination_ring", 515, {"overcooked.no_fixed": 1}), ("multiplayer_schelling", 130, {})])
+def test_plain_stream_out_equals_write_through(layout, n, knobs, hip_lib):
+    """The single-pass stream-out uses write-through stores, or ordinary ones where the slab is larger than the Infinity
+    Cache and a group's slab is not whole 128-byte lines (chosen at construction; `overcooked.whole_store` forces either).
+    Both instantiations of every kernel family (specialised, two groups per wave, generic, multi-step): same tensors."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params(layout, 45)
+    P = params["num_players"]
+    with debug_knobs({**knobs, "overcooked.whole_store": 1}):
+        through = make_sim(params, n)
+    with debug_knobs({**knobs, "overcooked.whole_store": 2}):
+        plain = make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    for t in range(90):
+        if t % 3 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            through.step_with_actions(a)
+            plain.step_with_actions(a)
+        elif t % 3 == 1:
+            through.rollout_random(3, seed=5, first_step=3 * t)
+            plain.rollout_random(3, seed=5, first_step=3 * t)
+        else:
+            seq = torch.randint(0, 6, (4, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            through.step_sequence(seq)
+            plain.step_sequence(seq)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(through, get)().to_torch(), getattr(plain, get)().to_torch()), f"{get}, step {t}"
+    through.close()
+    plain.close()
+
+
 def test_steps_captured_in_a_hip_graph_equal_eager_steps(hip_lib):
     """The C ABI only enqueues on the caller's stream (no host synchronisation, no allocation): step calls can be
     captured with torch.cuda.graph like any other stream work and replayed (bench.py's `graph_replay` leg).
