@@ -2147,18 +2147,22 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         }
         // Stores of the single-pass stream-out (stream_store_rsrc): write-through, except where the slab is larger than the
         // Infinity Cache AND a group's slab is not whole 128-byte lines -- then ordinary stores, which the L2 merges
-        const auto plain_for = [&](uint32_t group_worlds) {
+        // (the multi-step launches rewrite the same lines step after step and do better with ordinary stores for such groups
+        // at every size: asymmetric_advantages 32768 worlds 10.6 -> 9.3 us per step, 65536 21.2 -> 18.6, coordination_ring
+        // 6.61 -> 6.44; the single step inside the cache does not: coordination_ring 10.5 vs 12.0, asymmetric_advantages 15.6 vs 17.3)
+        const auto plain_for = [&](uint32_t group_worlds, bool multi_step) {
             const int64_t knob = mrl::debug_get("overcooked.whole_store", 0);  // 0 by slab size and alignment, 1 write-through, 2 plain
             const uint64_t slab = (uint64_t)N * a.block_bytes;
-            return knob ? knob == 2 : (slab > (256ull << 20) && ((uint64_t)group_worlds * a.block_bytes) % 128u != 0);
+            const bool whole_lines = ((uint64_t)group_worlds * a.block_bytes) % 128u == 0;
+            return knob ? knob == 2 : (!whole_lines && (multi_step || slab > (256ull << 20)));
         };
-        const bool plain = plain_for(wpw);
+        const bool plain = plain_for(wpw, false), plain_multi = plain_for(wpw, true);
         {
             const bool pairs = a.P == 2 && !sim->generic;  // two-player layouts (all five standard ones) exchange through DPP instead of LDS
             sim->generic_step = pairs ? (plain ? &mrl_overcooked_step<false, 2, true> : &mrl_overcooked_step<false, 2, false>)
                                       : (plain ? &mrl_overcooked_step<false, 0, true> : &mrl_overcooked_step<false, 0, false>);
-            sim->generic_rollout = pairs ? (plain ? &mrl_overcooked_rollout<2, true> : &mrl_overcooked_rollout<2, false>)
-                                         : (plain ? &mrl_overcooked_rollout<0, true> : &mrl_overcooked_rollout<0, false>);
+            sim->generic_rollout = pairs ? (plain_multi ? &mrl_overcooked_rollout<2, true> : &mrl_overcooked_rollout<2, false>)
+                                         : (plain_multi ? &mrl_overcooked_rollout<0, true> : &mrl_overcooked_rollout<0, false>);
         }
         if (sim->lds_bytes > 65536) {
             MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sim->generic_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sim->lds_bytes));
@@ -2188,8 +2192,8 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
                                   : &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, false>;       \
         sim->fixed_kernel_i64 = plain ? &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, true>      \
                                       : &mrl_overcooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true, false>;    \
-        sim->fixed_rollout = plain ? &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>            \
-                                   : &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false>;          \
+        sim->fixed_rollout = plain_multi ? &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>      \
+                                         : &mrl_overcooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false>;    \
         sim->fixed_name = "mrl_overcooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", false>";      \
         if (groups == 2) {                                                                                          \
             sim->groups_kernel = plain ? &mrl_overcooked_step_groups_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false, 2, true>     \
@@ -2275,8 +2279,8 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             uint32_t stride = 0;
 #define MRL_WIDE(C_, W2_, WIDTH_, POTS_, HOLD_)                                                                             \
     if (!sim->wide_rollout && a.C == C_ && rw == W2_ && a.W == WIDTH_ && a.num_pots == POTS_ && holders.size() == HOLD_) {                      \
-        sim->wide_rollout = plain_for(rw) ? &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, true>             \
-                                          : &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, false>;           \
+        sim->wide_rollout = plain_for(rw, true) ? &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, true>       \
+                                                : &mrl_overcooked_rollout_fixed<C_, W2_, WIDTH_, POTS_, HOLD_, false>;     \
         stride = fixed_layout(C_, W2_).stride;                                                                      \
     }
             MRL_WIDE(20, 16, 5, 1, 6)  // cramped_room
