@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t swap_pair(uint32_t v)
 // 16-byte write-through (sc1) store through a buffer descriptor: the observation slab is written once and
 // not read by the kernel; write-through streams it out while the waves still work instead of leaving dirty
 // lines for the end-of-kernel write-back (measured in overcooked.hip).  Out-of-range offsets are dropped.
+// kPlain: ordinary stores -- for groups whose slab is not whole 128-byte lines, in the multi-step launches and wherever
+// the slab is larger than the Infinity Cache (two write-through halves of a line cost a read-modify-write each there;
+// the L2 merges ordinary ones: overcooked.hip, stream_store_rsrc).
+template <bool kPlain = false>
 __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_offset, const uint4 &v)
 {
     u32x4 r;
@@ -89,7 +93,7 @@ __device__ __forceinline__ void stream_store_rsrc(__amdgpu_buffer_rsrc_t rsrc, u
     r.y = v.y;
     r.z = v.z;
     r.w = v.w;
-    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, 16);  // aux bit 4 = sc1
+    __builtin_amdgcn_raw_buffer_store_b128(r, rsrc, (int)byte_offset, 0, kPlain ? 0 : 16);  // aux bit 4 = sc1
 }
 
 // Cell-index delta of a move: NORTH -W, SOUTH +W, EAST +1, WEST -1, STAY / INTERACT 0, packed as signed

@@ -2153,7 +2153,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         const auto plain_for = [&](uint32_t group_worlds, bool multi_step) {
             const int64_t knob = mrl::debug_get("overcooked.whole_store", 0);  // 0 by slab size and alignment, 1 write-through, 2 plain
             const uint64_t slab = (uint64_t)N * a.block_bytes;
-            const bool whole_lines = ((uint64_t)group_worlds * a.block_bytes) % 128u == 0;
+            const bool whole_lines = ((uint64_t)group_worlds * a.block_bytes) % 64u == 0;  // (64: Simplecooked random0's 8000-byte groups, half a 128-byte line off, do not care)
             return knob ? knob == 2 : (!whole_lines && (multi_step || slab > (256ull << 20)));
         };
         const bool plain = plain_for(wpw, false), plain_multi = plain_for(wpw, true);

@@ -274,7 +274,7 @@ constexpr int kHoldPerLane = 4;     // 256 holder-table entries per group (direc
 constexpr int kTerrPosPerLane = 4;  // rows of one world <= 2 * 100
 constexpr int kGroupTerrPerLane = 7;  // rows of one GROUP in the flat mode (the standard layouts need 320..400)
 
-template <bool kInit, int kP>
+template <bool kInit, int kP, bool kPlain = false>
 __device__ __forceinline__ void step_body(const SimpleParams &p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -523,10 +523,10 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
             const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
             const uint32_t last = body - 1u;
             const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
-            stream_store_rsrc(out, ka << 4, va);
-            stream_store_rsrc(out, kb << 4, vb);
-            stream_store_rsrc(out, kc << 4, vc);
-            stream_store_rsrc(out, kd << 4, vd);
+            stream_store_rsrc<kPlain>(out, ka << 4, va);
+            stream_store_rsrc<kPlain>(out, kb << 4, vb);
+            stream_store_rsrc<kPlain>(out, kc << 4, vc);
+            stream_store_rsrc<kPlain>(out, kd << 4, vd);
         }
         const uint32_t done_bytes = head + (body << 4);
         if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
@@ -545,10 +545,10 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
     }
 }
 
-template <bool kInit, int kP>
+template <bool kInit, int kP, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_simplecooked_step(const SimpleParams p)
 {
-    step_body<kInit, kP>(p);
+    step_body<kInit, kP, kPlain>(p);
 }
 
 // The two-player step for ONE layout size known at compile time (kC cells in rows of kWidth, kPots pots, kW worlds
@@ -593,7 +593,7 @@ __device__ __forceinline__ SimpleParams fixed_simple_params(const SimpleParams &
 // The first fourteen argument dwords are separate scalars so that the command processor preloads them into SGPRs
 // (-amdgpu-kernarg-preload-count in the Makefile; overcooked.hip, MRL_HOT_ARGS): what a wave needs to find its worlds
 // and request its loads.  The struct carries everything else.
-template <int kC, int kW, int kWidth, int kPots, int kHold, int kSource = 0>
+template <int kC, int kW, int kWidth, int kPots, int kHold, int kSource = 0, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock)
     mrl_simplecooked_step_fixed(uint32_t *hot_cell_obj, uint2 *hot_players, int2 *hot_clock, const void *hot_actions, const uint32_t *hot_consts,
                                 const uint16_t *hot_terr_off, uint32_t hot_num_worlds, uint32_t hot_per_xcd, const SimpleParams p)
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(kBlock)
     q.num_worlds = hot_num_worlds;
     q.per_xcd = hot_per_xcd;
     if (kSource != 2) q.sample = 0;
-    step_body<false, 2>(q);
+    step_body<false, 2, kPlain>(q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(kBlock)
 // launches: cell objects in LDS, players and clocks in registers, the observation tile zeroed and given its terrain
 // bytes once -- a step patches what is dynamic now, streams the tile out and puts the patched rows back.
 // ---------------------------------------------------------------------------------------------
+template <bool kPlain>
 __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
                                              const int32_t *action_seq)
 {
@@ -763,10 +764,10 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
                 const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
                 const uint32_t last = body - 1u;
                 const uint4 va = src[min(ka, last)], vb = src[min(kb, last)], vc = src[min(kc, last)], vd = src[min(kd, last)];
-                stream_store_rsrc(out, ka << 4, va);
-                stream_store_rsrc(out, kb << 4, vb);
-                stream_store_rsrc(out, kc << 4, vc);
-                stream_store_rsrc(out, kd << 4, vd);
+                stream_store_rsrc<kPlain>(out, ka << 4, va);
+                stream_store_rsrc<kPlain>(out, kb << 4, vb);
+                stream_store_rsrc<kPlain>(out, kc << 4, vc);
+                stream_store_rsrc<kPlain>(out, kd << 4, vd);
             }
             const uint32_t done_bytes = body << 4;
             if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = tile[done_bytes + lane];
@@ -787,17 +788,18 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
     }
 }
 
+template <bool kPlain>
 __global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout(const SimpleParams p, uint32_t num_steps, uint64_t seed, uint32_t first_step,
                                                                    const int32_t *action_seq)
 {
-    rollout_body(p, num_steps, seed, first_step, action_seq);
+    rollout_body<kPlain>(p, num_steps, seed, first_step, action_seq);
 }
 
-template <int kC, int kW, int kWidth, int kPots, int kHold>
+template <int kC, int kW, int kWidth, int kPots, int kHold, bool kPlain>
 __global__ void __launch_bounds__(kBlock) mrl_simplecooked_rollout_fixed(const SimpleParams p, uint32_t num_steps, uint64_t seed,
                                                                          uint32_t first_step, const int32_t *action_seq)
 {
-    rollout_body(fixed_simple_params<kC, kW, kWidth, kPots, kHold>(p), num_steps, seed, first_step, action_seq);
+    rollout_body<kPlain>(fixed_simple_params<kC, kW, kWidth, kPots, kHold>(p), num_steps, seed, first_step, action_seq);
 }
 
 __global__ void fill_ids(int32_t *world_id, int32_t *row_id, uint32_t rows, uint32_t n)
@@ -821,6 +823,8 @@ struct SimplecookedSim final : mrl_sim {
     using FixedKernel = void (*)(uint32_t *, uint2 *, int2 *, const void *, const uint32_t *, const uint16_t *, uint32_t, uint32_t, const SimpleParams);
     FixedKernel fixed_kernel[3] = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
     void (*fixed_rollout)(const SimpleParams, uint32_t, uint64_t, uint32_t, const int32_t *) = nullptr;
+    void (*generic_rollout)(const SimpleParams, uint32_t, uint64_t, uint32_t, const int32_t *) = nullptr;
+    void (*generic_step)(const SimpleParams) = nullptr;  // mrl_simplecooked_step<false, P, store flavour>
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
@@ -837,10 +841,8 @@ struct SimplecookedSim final : mrl_sim {
             const void *hot_actions = source == 1 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
             hipLaunchKernelGGL(fixed_kernel[source], dim3(grid), dim3(kBlock), lds_bytes, stream, a.cell_obj, a.players, a.clock, hot_actions,
                                a.consts, a.terr_off, a.num_worlds, a.per_xcd, a);
-        } else if (a.P == 2) {
-            hipLaunchKernelGGL((mrl_simplecooked_step<false, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         } else {
-            hipLaunchKernelGGL((mrl_simplecooked_step<false, 1>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+            hipLaunchKernelGGL(generic_step, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         }
         MRL_HIP(hipGetLastError());
     }
@@ -871,7 +873,7 @@ struct SimplecookedSim final : mrl_sim {
         if (fixed_rollout)
             hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
         else
-            hipLaunchKernelGGL(mrl_simplecooked_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
+            hipLaunchKernelGGL(generic_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
         MRL_HIP(hipGetLastError());
         return true;
     }
@@ -1098,13 +1100,28 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
                            : 0u;
             a.hold_entries = (uint32_t)hold_tab.size();
         }
+        // store flavour of the stream-out (grid_common.hpp, stream_store_rsrc): ordinary stores iff a group's slab is not whole
+        // 128-byte lines and either the launch is a multi-step one or the slab exceeds the 256 MiB Infinity Cache
+        const auto plain_for = [&](bool multi_step) {
+            const int64_t knob = mrl::debug_get("overcooked.whole_store", 0);  // 0 that rule, 1 write-through, 2 plain
+            const bool whole_lines = ((uint64_t)wpw * a.block_bytes) % 64u == 0;  // (64: Simplecooked random0's 8000-byte groups, half a 128-byte line off, do not care)
+            return knob ? knob == 2 : (!whole_lines && (multi_step || (uint64_t)N * a.block_bytes > (256ull << 20)));
+        };
+        const bool plain = plain_for(false), plain_multi = plain_for(true);
+        sim->generic_step = a.P == 2 ? (plain ? &mrl_simplecooked_step<false, 2, true> : &mrl_simplecooked_step<false, 2, false>)
+                                     : (plain ? &mrl_simplecooked_step<false, 1, true> : &mrl_simplecooked_step<false, 1, false>);
+        sim->generic_rollout = plain_multi ? &mrl_simplecooked_rollout<true> : &mrl_simplecooked_rollout<false>;
 #define MRL_FIXED(C_, WPW_, WIDTH_, POTS_, HOLD_)                                                                                   \
     if (!sim->fixed_kernel[0] && a.P == 2 && a.C == C_ && a.W == WIDTH_ && a.num_pots == POTS_ && a.wpw == WPW_ && a.flat && a.direct && \
         holders.size() == HOLD_ && !mrl::debug_get("overcooked.no_fixed", 0)) {                                                      \
-        sim->fixed_kernel[0] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 0>;                                      \
-        sim->fixed_kernel[1] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 1>;                                      \
-        sim->fixed_kernel[2] = &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 2>;                                      \
-        sim->fixed_rollout = &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_>;                                        \
+        sim->fixed_kernel[0] = plain ? &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 0, true>                         \
+                                     : &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 0, false>;                       \
+        sim->fixed_kernel[1] = plain ? &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 1, true>                         \
+                                     : &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 1, false>;                       \
+        sim->fixed_kernel[2] = plain ? &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 2, true>                         \
+                                     : &mrl_simplecooked_step_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, 2, false>;                       \
+        sim->fixed_rollout = plain_multi ? &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, true>                     \
+                                         : &mrl_simplecooked_rollout_fixed<C_, WPW_, WIDTH_, POTS_, HOLD_, false>;                   \
         sim->fixed_name = "mrl_simplecooked_step_fixed<" #C_ ", " #WPW_ ", " #WIDTH_ ", " #POTS_ ", " #HOLD_ ", 0>";                 \
     }
         // the five standard old-style layouts at the batch sizes where they get 8 worlds per wave: cells, worlds per wave,

@@ -155,6 +155,38 @@ def test_direct_patch_equals_searched(layout, n, hip_lib):
     searched.close()
 
 
+@pytest.mark.parametrize("layout,n,knobs", [("random0", 4099, {"overcooked.wpw": 8}), ("unident_s", 515, {"overcooked.no_fixed": 1})])
+def test_plain_stream_out_equals_write_through(layout, n, knobs, hip_lib):
+    """Write-through or ordinary stores for the stream-out (chosen at construction by group alignment, slab size and kind of
+    launch; `overcooked.whole_store` forces either): both instantiations of the specialised, generic and multi-step kernels
+    leave the same tensors."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_simplecooked_layout_params(layout, 45)
+    P = params["num_players"]
+    with debug_knobs({**knobs, "overcooked.whole_store": 1}):
+        through = make_sim(params, n)
+    with debug_knobs({**knobs, "overcooked.whole_store": 2}):
+        plain = make_sim(params, n)
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    for t in range(90):
+        if t % 3 == 0:
+            a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            through.step_with_actions(a)
+            plain.step_with_actions(a)
+        elif t % 3 == 1:
+            through.rollout_random(3, seed=5, first_step=3 * t)
+            plain.rollout_random(3, seed=5, first_step=3 * t)
+        else:
+            seq = torch.randint(0, 6, (4, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+            through.step_sequence(seq)
+            plain.step_sequence(seq)
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(through, get)().to_torch(), getattr(plain, get)().to_torch()), f"{get}, step {t}"
+    through.close()
+    plain.close()
+
+
 def test_device_random_policy_and_sequence(hip_lib, oracle_lib):
     """mrl_rollout_random draws the documented stream (all steps of a call in one launch, state and tile resident);
     mrl_step_sequence runs an action array the same way; both equal the oracle and one launch per step."""
