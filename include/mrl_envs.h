@@ -346,8 +346,10 @@ uint64_t mrl_bytes_per_world_step(const mrl_sim *sim);
 void mrl_destroy(mrl_sim *sim);
 
 /* Test and measurement knobs, consulted by the NEXT mrl_*_create (the library reads no environment
- * variable).  Keys: overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.no_share,
- * overcooked.variant, hanabi.variant, hanabi.no_persistent, cartpole.no_persistent, fused_step,
+ * variable).  Keys (the list with their meanings: csrc/capi.hip, kDebugKeys): overcooked.wpw, overcooked.whole_max,
+ * overcooked.lds_max, overcooked.no_share, overcooked.no_fixed, overcooked.no_direct, overcooked.groups,
+ * overcooked.whole_store, overcooked.store_policy, overcooked.wide_rollout, overcooked.variant, hanabi.variant,
+ * hanabi.no_persistent, cartpole.no_persistent, fused_step (0 by batch size, 1 one launch, 2 two launches),
  * inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
  * No reference counterpart (the reference has MADRONA_* environment variables for its JIT cache only). */
 int mrl_debug_set(const char *key, int64_t value);
