@@ -2059,7 +2059,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // 9400 admits four worlds of a 9x5 layout (asymmetric_advantages: 25.4 -> 21.7 us per launch at 32768
         // worlds against two worlds per wave); larger tiles were measured and lose (8 worlds of a 5x5 layout:
         // 15.5 vs 12.4 us, 8 of counter_circuit 20.0 vs 16.7, 16 of cramped_room 12.8 vs 10.8)
-        const uint32_t kWholeTileMax = (uint32_t)mrl::debug_get("overcooked.whole_max", 9400);  // knobs: experiments and tests only
+        uint32_t kWholeTileMax = (uint32_t)mrl::debug_get("overcooked.whole_max", 9400);  // knobs: experiments and tests only
         const uint32_t lds_max = (uint32_t)mrl::debug_get("overcooked.lds_max", 65536);
         auto layout = [&](uint32_t wpw) {
             auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
@@ -2103,6 +2103,18 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             uint32_t cand = wpw;
             while (cand > 1 && (layout(cand), !a.whole)) cand >>= 1;
             if ((layout(cand), a.whole)) wpw = cand;
+            // A world that does not fit the 9400-byte tile but fits 16 KB (two players on up to 255 cells, four on up to 113)
+            // still does better as ONE wave's single-pass tile than through the multi-pass row assembly once there are a few
+            // hundred worlds (two workgroups per CU then): many_player_layout with 2 players, us per step multi-pass / single-
+            // pass -- 100 worlds 7.1 / 7.4, 1000 9.6 / 8.3, 4000 29.3 / 18.7, 10000 50.8 / 41.5, 32768 140 / 116
+            if (!a.whole && N >= 512 && !mrl::debug_get("overcooked.whole_max", 0)) {
+                const uint32_t keep = kWholeTileMax;
+                kWholeTileMax = 16384;
+                if ((layout(1), a.whole))
+                    wpw = 1;
+                else
+                    kWholeTileMax = keep;
+            }
         }
         while (wpw > 1 && (layout(wpw) > lds_max || (uint64_t)wpw * a.rows * a.rows >= (1ull << 32) ||
                            (uint64_t)wpw * a.C * a.C >= (1ull << 32)))
