@@ -18,6 +18,7 @@ static const char *const kDebugKeys[] = {
     "overcooked.whole_max",  // largest single-pass observation tile, bytes
     "overcooked.lds_max",    // LDS budget per workgroup, bytes
     "overcooked.share_max_players",  // experiment: up to how many players the four waves of a workgroup share one world of a large layout
+    "overcooked.share_private",  // 1: waves that share a world keep a private copy of its state each (step_body) instead of one per workgroup (team_body)
     "overcooked.no_share",   // 1: never let the waves of a workgroup share one world
     "overcooked.lds_pad",    // experiment: extra LDS bytes per workgroup (limits how many are resident per CU)
     "overcooked.no_fixed",   // 1: never use the kernels specialised for one layout size

@@ -97,6 +97,8 @@ struct StepParams {
     uint32_t whole;        // a group's whole observation slab fits one LDS tile: single-pass encode
     uint32_t share;        // the waves of a workgroup share ONE world (few worlds x very large observations): each
                            // steps it redundantly, takes every kWavesPerBlock-th pass of its rows; wave 0 stores the state
+    uint32_t team;         // share, with ONE copy of the world's state in LDS for the workgroup (team_body); off_tile / lds_wave_stride
+                           // then place the four waves' row tiles behind that copy
     uint32_t steady;       // all passes of a wave share one alignment and cover whole worlds: zero-fill once
     uint32_t tail_even;    // rows' 16-byte tails are 2-byte aligned in the LDS tile (P even)
     uint32_t private_consts;  // <= 4 players and <= 4 pots: start cells and pots travel in kernel arguments, the terrain
@@ -1291,6 +1293,200 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     STAMP_REALTIME(14);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few worlds of a very large layout (p.share): the four waves of a workgroup work on ONE world.  In step_body each of them
+// keeps its own copy of the world in LDS and steps it redundantly; that copy (cells, players, cell -> player map, the
+// 16-byte tail of every cell: 6-7 KB) times four is what decides how many workgroups fit a CU, and at the reference's
+// 1000-environment table the launch then needs a second generation of workgroups: many_player_layout with 4 players
+// takes 12.7 us per step at 768 worlds and 18.3 at 800 (three 45 KB workgroups per CU); with 8 players 15.9 at 512
+// and 25.7 at 600.  Here the workgroup keeps ONE copy: all 256 threads bring the cells in, wave 0 steps the world (lane =
+// player), all threads work out the cells' tails, then every wave assembles and streams every fourth pass of rows from
+// its own tile as before.  Three workgroup barriers; 25 KB (4 players) / 36 KB (8) of LDS per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <bool kInit>
+__device__ __forceinline__ void team_body(const StepParams &p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    constexpr int kConstWordsPerThread = (kConstBytes / 4 + kBlock - 1) / kBlock;
+    uint32_t const_word[kConstWordsPerThread];
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++) const_word[j] = tid + j * kBlock < kConstBytes / 4 ? p.consts[tid + j * kBlock] : 0u;
+    const uint8_t *s_terrain = smem + kConstTerrain;
+    const uint8_t *s_start = smem + kConstStart;
+    const uint8_t *s_pots = smem + kConstPots;
+    const uint32_t logical_block = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
+    const uint32_t w0 = logical_block;  // the workgroup's world
+    const uint32_t P = p.P, C = p.C, N = p.num_worlds, F = p.F, shift = 5 * P;
+    if (w0 >= N) return;  // the whole workgroup (the grid is rounded up to a multiple of eight)
+    uint8_t *base = smem + kConstBytes;
+    uint32_t *s_obj = reinterpret_cast<uint32_t *>(base);              // [C]
+    uint32_t *s_pl = reinterpret_cast<uint32_t *>(base + p.off_pl);    // [P][2]
+    uint32_t *s_x = reinterpret_cast<uint32_t *>(base + p.off_x);      // transition scratch (wave 0)
+    uint32_t *s_sum = reinterpret_cast<uint32_t *>(base + p.off_sum);
+    uint32_t *s_blk = s_sum + 1;
+    uint8_t *s_cur = base + p.off_cur;                                 // [C] cell -> player
+    uint8_t *s_flags = base + p.off_flags;
+    uint4 *s_tail = reinterpret_cast<uint4 *>(base + p.off_tail);      // [C]
+    uint8_t *s_tile = base + p.off_tile + wib * p.lds_wave_stride;     // this wave's row tile
+
+    // ---- load: the cells by all threads, the players by wave 0 ----
+    const bool mine = wib == 0 && lane < P;  // lane = player
+    uint32_t posori = 0, held = kItemNone, act = A_STAY;
+    int32_t t_loaded = 0;
+    if (!kInit) {
+        const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
+        const uint32_t cell_reg = tid < C ? g_obj[tid] : 0u;  // C <= 255 < kBlock
+        uint2 pl_reg = make_uint2(0, 0);
+        uint32_t a_raw = A_STAY;
+        if (mine) {
+            pl_reg = p.players[(size_t)w0 * P + lane];
+            a_raw = load_action(p, (size_t)lane * N + w0);
+        }
+        if (wib == 0) t_loaded = p.timestep[w0];
+        if (tid < C) s_obj[tid] = cell_reg;
+        if (mine) {
+            posori = pl_reg.x & 0xFFFFu;
+            held = pl_reg.y;
+            act = a_raw <= A_INTERACT ? a_raw : (uint32_t)A_STAY;
+            if (p.actions64) p.action_mirror[(size_t)lane * N + w0] = (int32_t)a_raw;
+        }
+    }
+    if (tid < (C + 3u) >> 2) reinterpret_cast<uint32_t *>(s_cur)[tid] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < kConstWordsPerThread; j++)
+        if (tid + j * kBlock < kConstBytes / 4) reinterpret_cast<uint32_t *>(smem)[tid + j * kBlock] = const_word[j];
+    __syncthreads();
+
+    // ---- step: wave 0, lane = player ----
+    int32_t reward_world = 0, t = 0;
+    bool reset_now = kInit;
+    if (wib == 0) {
+        if (!kInit) {
+            transition_lanes<0>(p, s_terrain, s_obj, s_x, s_sum, s_blk, P, lane, mine, 0u, lane, act, posori, held, reward_world);
+            tick_pots(p, s_pots, s_obj, 1u, lane);
+            t = t_loaded + 1;
+            reset_now = (int64_t)t >= p.horizon;
+        }
+        if (reset_now) {  // wave-uniform: one world
+            t = 0;
+            posori = (uint32_t)s_start[mine ? lane : 0u] | (A_NORTH << 8);
+            held = kItemNone;
+            for (uint32_t i = lane; i < C; i += kWave) s_obj[i] = kItemNone;
+        }
+        if (mine) {
+            reinterpret_cast<uint2 *>(s_pl)[lane] = make_uint2(posori, held);
+            s_cur[posori & 0xFFu] = (uint8_t)lane;
+        }
+        if (lane == 0) s_flags[0] = (p.horizon - (int64_t)t < 40) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // ---- the cells' viewer-independent tails: all threads ----
+    if (tid < C) {
+        const uint32_t who = s_cur[tid];
+        const uint32_t h = who != 0xFF ? s_pl[who * 2 + 1] : kItemNone;
+        s_tail[tid] = cell_tail(p, s_terrain[tid], s_obj[tid], h, s_flags[0]);
+    }
+    __syncthreads();
+
+    // ---- rows: every fourth pass of kRowsPerPass rows per wave (as step_body's multi-pass loop, one world) ----
+    constexpr uint32_t kRowsPerLane = kRowsPerPass / kWave;
+    const uint32_t total_rows = p.rows;
+    uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    for (uint32_t r0 = wib * kRowsPerPass; r0 < total_rows; r0 += kWavesPerBlock * kRowsPerPass) {
+        const uint32_t nrows = min((uint32_t)kRowsPerPass, total_rows - r0);
+        const uint32_t nbytes = nrows * F;
+        uint8_t *g = gobs + (size_t)r0 * F;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 15u);  // tile and slab congruent mod 16
+        uint8_t *tile = s_tile + mis;
+        const uint32_t nchunks = (mis + nbytes + 15u) >> 4;
+        for (uint32_t k = lane; k < nchunks; k += kWave) reinterpret_cast<uint4 *>(s_tile)[k] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        bool valid[kRowsPerLane], occupied[kRowsPerLane];
+        uint32_t cell[kRowsPerLane], viewer[kRowsPerLane], who[kRowsPerLane], ori[kRowsPerLane];
+        uint4 tl[kRowsPerLane];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            const uint32_t tr = lane * kRowsPerLane + j;
+            valid[j] = tr < nrows;
+            const uint32_t r = r0 + tr;
+            viewer[j] = __umulhi(r, p.inv_c);
+            cell[j] = valid[j] ? r - __umul24(viewer[j], C) : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            tl[j] = s_tail[cell[j]];
+            who[j] = s_cur[cell[j]];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            occupied[j] = valid[j] && who[j] != 0xFF;
+            ori[j] = (s_pl[(occupied[j] ? who[j] : 0u) * 2] >> 8) & 0xFF;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRowsPerLane; j++) {
+            const uint32_t row = __umul24(lane * kRowsPerLane + j, F);
+            const uint32_t cls = p.tail_even ? ((mis + j * F + shift) & 3u) : 1u;
+            if (valid[j]) lds_store_tail(tile + row + shift, tl[j], cls);
+            const uint32_t rel = who[j] == viewer[j] ? 0u : (who[j] < viewer[j] ? who[j] + 1u : who[j]);
+            if (occupied[j]) {
+                tile[row + rel] = 1;
+                tile[row + P + 4 * rel + ori[j]] = 1;
+            }
+        }
+        wave_lds_sync();
+        const uint32_t head = min((16u - mis) & 15u, nbytes);
+        if (lane < head) g[lane] = tile[lane];
+        const uint32_t body = (nbytes - head) >> 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile + head);
+        uint4 *dst = reinterpret_cast<uint4 *>(g + head);
+        for (uint32_t k0 = lane; k0 < body + lane; k0 += 4 * kWave) {
+            const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+            const bool ba = ka < body, bb = kb < body, bc = kc < body, bd = kd < body;
+            const uint4 va = src[ba ? ka : 0u], vb = src[bb ? kb : 0u], vc = src[bc ? kc : 0u], vd = src[bd ? kd : 0u];
+            if (p.store_policy == 0) {
+                if (ba) stream_store(dst + ka, va);
+                if (bb) stream_store(dst + kb, vb);
+                if (bc) stream_store(dst + kc, vc);
+                if (bd) stream_store(dst + kd, vd);
+            } else if (p.store_policy == 1) {
+                if (ba) dst[ka] = va;
+                if (bb) dst[kb] = vb;
+                if (bc) dst[kc] = vc;
+                if (bd) dst[kd] = vd;
+            } else {
+                if (ba) nt_store(dst + ka, va);
+                if (bb) nt_store(dst + kb, vb);
+                if (bc) nt_store(dst + kc, vc);
+                if (bd) nt_store(dst + kd, vd);
+            }
+        }
+        const uint32_t done_bytes = head + (body << 4);
+        if (lane < nbytes - done_bytes) g[done_bytes + lane] = tile[done_bytes + lane];
+        wave_lds_sync();
+    }
+
+    // ---- store: cells by all threads, the rest by wave 0 ----
+    if (tid < C) p.cell_obj[(size_t)w0 * C + tid] = s_obj[tid];
+    if (mine) {
+        p.players[(size_t)w0 * P + lane] = make_uint2(posori, held);
+        p.reward[(size_t)lane * N + w0] = reward_world;
+        if (lane == 0) {
+            p.timestep[w0] = t;
+            p.done[w0] = kInit ? 0 : (int32_t)reset_now;
+        }
+    }
+}
+
+template <bool kInit>
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_team(const StepParams p)
+{
+    team_body<kInit>(p);
+}
+
 template <bool kInit, int kP, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
 {
@@ -1806,7 +2002,11 @@ struct OvercookedSim final : mrl_sim {
         a.per_xcd = ((!init && groups_kernel) ? groups_grid : grid) >> 3;
         const void *hot_actions = a.actions64 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
-        if (init)
+        if (a.team && init)
+            hipLaunchKernelGGL((mrl_overcooked_step_team<true>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        else if (a.team)
+            hipLaunchKernelGGL((mrl_overcooked_step_team<false>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
+        else if (init)
             hipLaunchKernelGGL((mrl_overcooked_step<true, 0>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         else if (groups_kernel)
             hipLaunchKernelGGL(a.actions64 ? groups_kernel_i64 : groups_kernel, dim3(groups_grid), dim3(kBlock), lds_bytes, stream, a.cell_obj,
@@ -1934,6 +2134,7 @@ struct OvercookedSim final : mrl_sim {
     }
     const char *kernel_name() const override
     {
+        if (params.team) return "mrl_overcooked_step_team<false>";
         if (groups_kernel) return groups_name;
         if (fixed_kernel) return fixed_name;
         return params.P == 2 && !generic ? "mrl_overcooked_step<false, 2>" : "mrl_overcooked_step<false, 0>";
@@ -2189,6 +2390,26 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         // count on one lane, redundant in every sibling wave) more players lost (8: 36.8 / 32.6, 30: 564 / 521), with
         // the lane-per-player transition they no longer do (8: 30.7 / 30.8, 16: 82.7 / 86.7, 30: 253 / 260), so any count.
         a.share = (wpw == 1 && !a.whole && a.wpp == 0 && N < 8192 && P <= (uint32_t)mrl::debug_get("overcooked.share_max_players", 64) && !mrl::debug_get("overcooked.no_share", 0)) ? 1u : 0u;
+        if (a.share && !mrl::debug_get("overcooked.share_private", 0)) {
+            // team_body: one copy of the world's state per workgroup, the four row tiles behind it
+            auto up16 = [](uint32_t v) { return (v + 15u) & ~15u; };
+            a.team = 1;
+            a.off_pl = up16(a.C * 4);
+            a.off_x = a.off_pl + up16(a.P * 8);
+            a.off_sum = a.off_x + 128u * 4u;
+            a.off_cur = a.off_sum + 16u;
+            a.off_flags = a.off_cur + up16(a.C);
+            a.off_tail = a.off_flags + 64u;
+            a.off_tile = a.off_tail + a.C * 16u;
+            a.lds_wave_stride = tile_bytes;
+            sim->lds_bytes = kConstBytes + a.off_tile + kWavesPerBlock * tile_bytes + (uint32_t)mrl::debug_get("overcooked.lds_pad", 0);
+            if (sim->lds_bytes > 65536) {
+                MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step_team<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)sim->lds_bytes));
+                MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step_team<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)sim->lds_bytes));
+            }
+        }
         {
             // a kernel specialised for this layout size, if there is one and the parameters are exactly what it assumes
             auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_, uint32_t hold_) {

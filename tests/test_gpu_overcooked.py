@@ -181,6 +181,40 @@ def test_plain_stream_out_equals_write_through(layout, n, knobs, hip_lib):
     plain.close()
 
 
+@pytest.mark.parametrize("players,n,horizon", [(2, 50, 30), (3, 21, 22), (4, 35, 26), (8, 33, 30), (13, 17, 25), (30, 9, 20)])
+def test_shared_world_one_state_copy_equals_private_copies(players, n, horizon, hip_lib, oracle_lib):
+    """Few worlds of a large layout: the four waves of a workgroup share a world.  By default the workgroup keeps ONE copy of
+    the world's state in LDS (wave 0 steps it, all threads compute the cells' tails: `mrl_overcooked_step_team`);
+    `overcooked.share_private` = 1 gives every wave its own copy and a redundant transition.  Both equal the oracle."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    params = layouts.get_base_layout_params("many_player_layout", horizon, max_num_players=players)
+    P, C = params["num_players"], params["height"] * params["width"]
+    team = make_sim(params, n)
+    with debug_knobs({"overcooked.share_private": 1}):
+        private = make_sim(params, n)
+    assert "step_team" in team.kernel_name and "step_team" not in private.kernel_name
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    rng = np.random.default_rng(players)
+    assert np.array_equal(world_major(team).view(n, P, C, 5 * P + 16).cpu().numpy().astype(np.uint8), orc.obs)
+    for t in range(3 * horizon + 5):
+        acts = rng.integers(0, 5, size=(P, n)).astype(np.int32)
+        acts[rng.random((P, n)) < 0.35] = 5
+        orc.step(acts)
+        a = torch.from_numpy(acts).cuda().view(P, n, 1)
+        if t % 2 == 0:
+            team.step_with_actions(a)
+            private.step_with_actions(a)
+        else:
+            team.step_with_actions_i64(a.to(torch.int64))
+            private.step_with_actions_i64(a.to(torch.int64))
+        assert np.array_equal(world_major(team).view(n, P, C, 5 * P + 16).cpu().numpy().astype(np.uint8), orc.obs), f"obs differ at step {t}"
+        for get in ("observation_world_major_tensor", "reward_tensor", "done_tensor", "action_tensor", "state_objects_tensor", "state_players_tensor",
+                    "state_timestep_tensor"):
+            assert torch.equal(getattr(team, get)().to_torch(), getattr(private, get)().to_torch()), f"{get}, step {t}"
+    team.close()
+    private.close()
+
+
 def test_steps_captured_in_a_hip_graph_equal_eager_steps(hip_lib):
     """The C ABI only enqueues on the caller's stream (no host synchronisation, no allocation): step calls can be
     captured with torch.cuda.graph like any other stream work and replayed (bench.py's `graph_replay` leg).
@@ -310,7 +344,7 @@ def test_same_cell_interactions_in_player_order(layout, cap, n, variant, hip_lib
     orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
     with debug_knobs({"overcooked.variant": variant}):
         sim = make_sim(params, n)
-    assert sim.kernel_name.endswith("0>") == (variant == 1 or P != 2)
+    assert "step_team" in sim.kernel_name or sim.kernel_name.endswith("0>") == (variant == 1 or P != 2)  # (few worlds of a large layout: team kernel)
     o = world_major(sim).view(n, P, C, F)
     rng = np.random.default_rng(99)
     for t in range(150):
