@@ -2305,10 +2305,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             while (cand > 1 && (layout(cand), !a.whole)) cand >>= 1;
             if ((layout(cand), a.whole)) wpw = cand;
             // A world that does not fit the 9400-byte tile but fits 16 KB (two players on up to 255 cells, four on up to 113)
-            // still does better as ONE wave's single-pass tile than through the multi-pass row assembly once there are a few
-            // hundred worlds (two workgroups per CU then): many_player_layout with 2 players, us per step multi-pass / single-
-            // pass -- 100 worlds 7.1 / 7.4, 1000 9.6 / 8.3, 4000 29.3 / 18.7, 10000 50.8 / 41.5, 32768 140 / 116
-            if (!a.whole && N >= 512 && !mrl::debug_get("overcooked.whole_max", 0)) {
+            // still does better as ONE wave's single-pass tile than through the multi-pass row assembly once there are about a
+            // thousand worlds: many_player_layout with 2 players, us per step multi-pass (the waves of a workgroup share a world,
+            // team_body) / single-pass -- 512 worlds 6.6 / 7.7, 1000 8.5 / 8.4, 2000 14.5 / 10.4, 4000 22.9 / 18.6, 8000 38.3 / 34.0
+            if (!a.whole && N >= 1000 && !mrl::debug_get("overcooked.whole_max", 0)) {
                 const uint32_t keep = kWholeTileMax;
                 kWholeTileMax = 16384;
                 if ((layout(1), a.whole))

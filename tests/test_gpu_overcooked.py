@@ -77,7 +77,7 @@ def test_golden_vectors(path, hip_lib):
     ("many_player_layout", 22, 3, 21, 50),           # the same with an odd player count
     ("many_player_layout", 26, 4, 35, 60),
     ("cramped_room", 400, None, 40000, 12),          # 8 worlds per wave, ragged last group
-    ("many_player_layout", 30, 2, 600, 70),          # a 13 KB world as one wave's single-pass tile (from 512 worlds on)
+    ("many_player_layout", 30, 2, 1100, 70),         # a 13 KB world as one wave's single-pass tile (from 1000 worlds on)
     ("many_player_layout", 30, 2, 8200, 8),
 ])
 def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
