@@ -106,7 +106,9 @@ struct StepParams {
     uint32_t starts_w;        // start cells of the first four players, one byte each
     uint32_t off_terr;        // per-wave terrain copy (private_consts)
     uint32_t store_policy; // multi-pass stream-out: 0 sc1 write-through, 1 plain, 2 nt (chosen by slab size; mrl_debug_set overcooked.store_policy)
-    uint32_t patch;        // single-pass encode that only touches dynamic cells: the group's slab starts on a 16-byte boundary
+    uint32_t patch;        // single-pass encode that only touches dynamic cells (zero-filled tile + terrain bytes + patches)
+    uint32_t unaligned;    // ... whose group slabs do not all start on 16-byte boundaries (one or two big worlds per wave): the tile
+                           // is kept as misaligned as the slab, so 16-byte chunks line up; a few head bytes go out one by one
     const uint16_t *terr_off;  // device, [terr_entries]: per row of a GROUP, tile offset of its terrain one-hot byte, 0 = none
     uint32_t terr_entries;     // wpw * rows
     // p.direct (see patch_direct): the encode needs no search for what is dynamic.  Players only ever stand on AIR cells and
@@ -760,9 +762,12 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     // dropped by the bounds check, so the four-deep batches need no per-lane branches), then the odd tail bytes
     uint8_t *gobs = p.obs + (size_t)(w0 + l0) * p.block_bytes;
     const uint32_t nbytes = nl * p.block_bytes;
-    const uint32_t body = nbytes >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(tile + __umul24(l0, p.block_bytes));
-    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs, 0, (int)(body << 4), 0x00020000);
+    const uint8_t *from = tile + __umul24(l0, p.block_bytes);
+    const uint32_t head = p.unaligned ? min((16u - ((uint32_t)reinterpret_cast<uintptr_t>(gobs) & 15u)) & 15u, nbytes) : 0u;
+    if (lane < head) gobs[lane] = from[lane];
+    const uint32_t body = (nbytes - head) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(from + head);
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs + head, 0, (int)(body << 4), 0x00020000);
     // (reads past the body stay inside the workgroup's LDS or return zero; their stores are dropped by the bounds check)
     uint32_t k0 = lane;
     for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
@@ -774,8 +779,8 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
         stream_store_rsrc<kPlain>(out, kd << 4, vd);
     }
     for (; k0 < body + lane; k0 += kWave) stream_store_rsrc<kPlain>(out, k0 << 4, src[k0]);
-    const uint32_t done_bytes = body << 4;
-    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = reinterpret_cast<const uint8_t *>(src)[done_bytes + lane];
+    const uint32_t done_bytes = head + (body << 4);
+    if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = from[done_bytes + lane];
     if constexpr (kRestore) {
         wave_lds_sync();
         if (p.direct) patch_direct<kP, true>(p, s_obj, s_flags, hold, tile, P, nl, active, wl, q, posori, held);
@@ -977,6 +982,8 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     int32_t t_loaded = 0;
     TerrPos tpos;
     HoldTab hold{};
+    // p.unaligned: the tile of the patch encode is as misaligned as the group's slab in HBM
+    const uint32_t patch_mis = p.unaligned ? (uint32_t)(reinterpret_cast<uintptr_t>(p.obs + (size_t)w0 * p.block_bytes) & 15u) : 0u;
     // ---------------- load: HBM slab -> LDS (straight copies) ----------------
     // All global loads of the group are issued before the first one is consumed (explicitly
     // batched: a plain copy loop waits for each load before issuing the next, which measured
@@ -1001,7 +1008,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         if (!p.direct)
             for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
-            tile_zero_addtid(s_tile, nw * p.block_bytes);
+            tile_zero_addtid(s_tile, nw * p.block_bytes + patch_mis);
         else if (p.whole)
             tile_zero(p, lane, s_tile, nw);
         if (p.direct) hold_request(p, lane, hold);  // not among the preloaded arguments: asked for behind the fill
@@ -1025,12 +1032,12 @@ __device__ __forceinline__ void step_body(const StepParams &p)
         if (!p.direct)
             for (uint32_t i = lane; i < (p.wpw * C + 3u) >> 2; i += kWave) reinterpret_cast<uint32_t *>(s_cur)[i] = 0xFFFFFFFFu;
         if (p.patch)
-            tile_zero_addtid(s_tile, nw * p.block_bytes);
+            tile_zero_addtid(s_tile, nw * p.block_bytes + patch_mis);
         else if (p.whole)
             tile_zero(p, lane, s_tile, nw);
         if (p.direct) hold_request(p, lane, hold);
     }
-    if (p.patch) terrain_deliver(p, tpos, s_tile, nw);
+    if (p.patch) terrain_deliver(p, tpos, s_tile + patch_mis, nw);
     if (private_consts) {
         if (lane * 4u < p.C) reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(s_terrain))[lane] = const_word[0];
         STAMP(7);
@@ -1126,7 +1133,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
             // patched, measured slower: 8.6 vs 8.25 us.)
             const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
             STAMP(4);
-            observe_patch<kP, false, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
+            observe_patch<kP, false, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, nullptr, s_list, ndyn, s_tile + patch_mis, P, w0, 0, nw, lane, hold, active,
                                      wl, q, posori, held);
             STAMP(5);
         } else
@@ -1553,6 +1560,7 @@ __device__ __forceinline__ StepParams fixed_params(const StepParams &p)
     q.private_consts = 1;
     q.terr_entries = kW * 2 * kC;
     q.direct = 1;
+    q.unaligned = 0;
     q.hold_entries = fixed_hold_entries(kW, kHold);
     q.off_pl = f.off_pl;
     q.off_x = f.off_x;
@@ -1663,6 +1671,7 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
     int32_t t = 0;
     uint8_t *s_prev = s_flags + 32;  // urgency flags as the tile holds them (wpw * 2 <= 64 players: wpw <= 32)
     HoldTab hold{};
+    const uint32_t patch_mis = p.unaligned ? (uint32_t)(reinterpret_cast<uintptr_t>(p.obs + (size_t)w0 * p.block_bytes) & 15u) : 0u;
     {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
         const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
@@ -1671,8 +1680,8 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         if (p.direct) hold_request(p, lane, hold);
         if (p.patch) {
             terrain_request(p, lane, tpos);
-            tile_zero_addtid(s_tile, nw * p.block_bytes);
-            terrain_deliver(p, tpos, s_tile, nw);
+            tile_zero_addtid(s_tile, nw * p.block_bytes + patch_mis);
+            terrain_deliver(p, tpos, s_tile + patch_mis, nw);
             if (lane < 32) s_prev[lane] = 0;
         }
         for (uint32_t i = lane; i < ncells; i += kWave) s_obj[i] = g_obj[i];
@@ -1742,8 +1751,8 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         if (p.patch) {
             // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
             const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
-            observe_patch<kP, true, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile, P, w0, 0, nw, lane, hold, active,
-                                             wl, q, posori, held);
+            observe_patch<kP, true, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile + patch_mis, P, w0, 0, nw, lane, hold,
+                                             active, wl, q, posori, held);
         } else {
             observe_whole<kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
@@ -2277,12 +2286,13 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             a.off_tail = a.off_list + up16(wpw * a.C * 2u);
             const uint32_t whole_tile = up16(wpw * a.block_bytes) + 32u;
             a.whole = (a.tail_even && whole_tile <= kWholeTileMax) ? 1u : 0u;
-            // with a background image the slab must start on a 16-byte boundary in every group
-            a.patch = (a.whole && ((uint64_t)wpw * a.block_bytes) % 16u == 0 && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave && wpw * a.block_bytes < 65536u) ? 1u : 0u;
+            // (group slabs that do not start on 16-byte boundaries -- one or two big worlds per wave -- keep tile and slab congruent)
+            a.patch = (a.whole && wpw * a.rows <= (uint32_t)kTerrPosPerLane * kWave && wpw * a.block_bytes < 65536u - 16u) ? 1u : 0u;
+            a.unaligned = (a.patch && ((uint64_t)wpw * a.block_bytes) % 16u != 0) ? 1u : 0u;  // (block_bytes is even here: tail_even)
             if (a.whole) {
                 a.off_tile = a.off_tail;
                 // with a.patch the tile is zeroed in whole 256-byte pieces (tile_zero_addtid)
-                a.lds_wave_stride = a.off_tile + (a.patch ? ((wpw * a.block_bytes + 255u) & ~255u) : whole_tile);
+                a.lds_wave_stride = a.off_tile + (a.patch ? ((wpw * a.block_bytes + (a.unaligned ? 15u : 0u) + 255u) & ~255u) : whole_tile);
             } else {
                 a.off_tile = a.off_tail + wpw * a.C * 16;
                 a.lds_wave_stride = a.off_tile + tile_bytes;
@@ -2305,10 +2315,11 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             while (cand > 1 && (layout(cand), !a.whole)) cand >>= 1;
             if ((layout(cand), a.whole)) wpw = cand;
             // A world that does not fit the 9400-byte tile but fits 16 KB (two players on up to 255 cells, four on up to 113)
-            // still does better as ONE wave's single-pass tile than through the multi-pass row assembly once there are about a
-            // thousand worlds: many_player_layout with 2 players, us per step multi-pass (the waves of a workgroup share a world,
-            // team_body) / single-pass -- 512 worlds 6.6 / 7.7, 1000 8.5 / 8.4, 2000 14.5 / 10.4, 4000 22.9 / 18.6, 8000 38.3 / 34.0
-            if (!a.whole && N >= 1000 && !mrl::debug_get("overcooked.whole_max", 0)) {
+            // still does better as ONE wave's single-pass tile than through the multi-pass row assembly once there are a few
+            // hundred worlds: many_player_layout with 2 players, us per step multi-pass (the waves of a workgroup share a world,
+            // team_body) / single-pass -- 256 worlds 5.8 / 6.0, 512 6.6 / 6.2, 768 7.6 / 6.6, 1000 8.5 / 6.9, 2000 14.5 / 9.1,
+            // 4000 22.9 / 16.0
+            if (!a.whole && N >= 384 && !mrl::debug_get("overcooked.whole_max", 0)) {
                 const uint32_t keep = kWholeTileMax;
                 kWholeTileMax = 16384;
                 if ((layout(1), a.whole))
@@ -2415,7 +2426,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
             auto matches = [&](uint32_t C_, uint32_t wpw_, uint32_t width_, uint32_t pots_, uint32_t hold_) {
                 const FixedLayout f = fixed_layout(C_, wpw_);
                 return a.P == 2 && !sim->generic && a.C == C_ && a.W == width_ && a.num_pots == pots_ && a.wpw == wpw_ && a.whole &&
-                       a.patch && a.direct && holders.size() == hold_ && !a.share && a.private_consts && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
+                       a.patch && !a.unaligned && a.direct && holders.size() == hold_ && !a.share && a.private_consts && a.off_pl == f.off_pl && a.off_sum == f.off_sum &&
                        a.off_cur == f.off_cur && a.off_flags == f.off_flags && a.off_terr == f.off_terr && a.off_list == f.off_list &&
                        a.off_tile == f.off_tile && a.lds_wave_stride == f.stride && !mrl::debug_get("overcooked.no_fixed", 0);
             };

@@ -77,7 +77,7 @@ def test_golden_vectors(path, hip_lib):
     ("many_player_layout", 22, 3, 21, 50),           # the same with an odd player count
     ("many_player_layout", 26, 4, 35, 60),
     ("cramped_room", 400, None, 40000, 12),          # 8 worlds per wave, ragged last group
-    ("many_player_layout", 30, 2, 1100, 70),         # a 13 KB world as one wave's single-pass tile (from 1000 worlds on)
+    ("many_player_layout", 30, 2, 1100, 70),         # a 13 KB world as one wave's single-pass tile (from 384 worlds on), slabs off 16-byte boundaries
     ("many_player_layout", 30, 2, 8200, 8),
 ])
 def test_against_oracle(layout, horizon, cap, n, steps, hip_lib, oracle_lib):
@@ -244,7 +244,8 @@ def test_steps_captured_in_a_hip_graph_equal_eager_steps(hip_lib):
 
 
 @pytest.mark.parametrize("layout,cap,n", [("cramped_room", None, 4099), ("counter_circuit", None, 1001), ("asymmetric_advantages", None, 515),
-                                          ("multiplayer_schelling", None, 130), ("cramped_room", None, 7)])
+                                          ("multiplayer_schelling", None, 130), ("cramped_room", None, 7),
+                                          ("many_player_layout", 2, 1003)])  # one 13260-byte world per wave: slabs off 16-byte boundaries
 def test_direct_patch_equals_searched(layout, cap, n, hip_lib):
     """The single-pass encode takes its dynamic rows from the player lanes and a table of holder cells (counters and pots a
     player can face); `overcooked.no_direct` makes it look for them through the cell -> player map instead.  Same tensors,
