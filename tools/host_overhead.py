@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Host-side cost of one step call (small batches are bound by it): microseconds per call of the pieces, measured with a
 32-world simulator so that the GPU is never the bottleneck."""
-import os, sys, time, ctypes
+import os
+import sys
+import time
+
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from madrona_rl_envs_playground_amd import _lib, layouts
+from madrona_rl_envs_playground_amd import layouts
 from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
 from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
 

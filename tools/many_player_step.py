@@ -1,5 +1,12 @@
-import sys, torch
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""us per step of the many_player_layout (15 x 17) with a given player count and batch:
+`python tools/many_player_step.py <players> <worlds> [knob=value ...]` (the rows of the reference README's many-player table)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madrona_rl_envs_playground_amd import _lib, layouts
 from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
 players, n = int(sys.argv[1]), int(sys.argv[2])
