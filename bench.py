@@ -15,6 +15,11 @@ independent, so ranks do not communicate inside the timed region of `value` (wea
 worlds per GPU).  N > 1 also times the `obs_gather` leg of BASELINE.json configs[3]: the same step
 followed by the RCCL all-gather of the world-major observation shards (34 MB per rank per step).
 
+`MRL_BENCH_FORCE_DIST=1 python bench.py --gpus 1 ...` runs the N > 1 protocol at world_size 1 (it starts ONE
+rank under torch.distributed.run): process group over `nccl` (= RCCL), the fences' barrier, the max-over-ranks
+all_reduce / all_gather on device tensors and the obs_gather leg's all_gather_into_tensor all execute on the
+one GPU a test box has (tests/test_gpu_nccl.py); the headline extras are skipped in that mode.
+
 Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barrier +
 `torch.cuda.synchronize()` on both sides, max over ranks.  One block is the contract; when K steps
 are shorter than 50 ms (K = 20 is 0.2 ms here) the block is repeated and the MEDIAN block is
@@ -61,8 +66,12 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def force_dist():
+    return os.environ.get("MRL_BENCH_FORCE_DIST") == "1"
+
+
 def spawn_ranks(args):
-    """--gpus N > 1 and no launcher: start the N ranks as a child job.  Nothing in THIS process has
+    """--gpus N > 1 (or MRL_BENCH_FORCE_DIST=1) and no launcher: start the N ranks as a child job.  Nothing in THIS process has
     touched the GPU (torch is not even imported), and the child is a child, never an exec."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -128,11 +137,14 @@ def run(args):
     # the multi-rank control flow can be exercised where only one card exists.  The driver's real runs
     # use one rank per GPU over RCCL.
     rehearse = world_size > 1 and os.environ.get("MRL_BENCH_REHEARSE") == "1"
+    # use_dist: the rank protocol (process group, barriers, reductions over ranks, gather leg) is in force.  Always for
+    # N > 1; at N = 1 only under MRL_BENCH_FORCE_DIST=1, which is how the nccl path is executed on a one-GPU box.
+    use_dist = world_size > 1 or force_dist()
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     backend = None
-    if world_size > 1:
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if rehearse else "nccl"
         if rehearse:
@@ -160,19 +172,19 @@ def run(args):
     obs = sim.observation_world_major_tensor().to_torch()
 
     def fence():
-        if world_size > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world_size == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def all_ranks(x):
-        if world_size == 1:
+        if not use_dist:
             return [x]
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         out = [torch.zeros_like(t) for _ in range(world_size)]
@@ -208,7 +220,7 @@ def run(args):
 
     # ---------------- N > 1: the step followed by the all-gather of the observation shards ----------------
     gather = None
-    if world_size > 1 and not args.no_gather_leg:
+    if use_dist and not args.no_gather_leg:
         gathered = torch.empty((world_size * n,) + tuple(obs.shape[1:]), dtype=obs.dtype, device=obs.device)
         gsteps, gwarm = (min(args.steps, 3), 1) if rehearse else (args.steps, min(args.warmup, 10))
 
@@ -248,10 +260,11 @@ def run(args):
     kernel_us = launches_us(lambda i: sim.step_with_actions(pool[i % args.pool]), k_launch)
 
     extras = {}
-    single = world_size == 1 and not args.no_extras
+    solo = world_size == 1 and not use_dist
+    single = solo and not args.no_extras
     stream = torch.cuda.current_stream().cuda_stream
     peak_measured = None
-    if world_size == 1:
+    if solo:
         # on-box bandwidth probes (second denominator): float4 copy and write-only streams over 1 GiB
         nbytes = 1 << 30
         a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -404,24 +417,24 @@ def run(args):
                        "per_rank_ms_per_step": per_rank_ms, "rank_min_ms_per_step": min(per_rank_ms), "rank_max_ms_per_step": max(per_rank_ms)},
             "roofline": roofline,
         }
-        if world_size > 1:
+        if use_dist:
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend,
                             "rehearsal_on_one_gpu": bool(rehearse)}
             if gather is not None:
                 out["obs_gather"] = gather
         out.update(extras)
-        if not args.no_cpu_baseline and world_size == 1:
+        if not args.no_cpu_baseline and solo:
             out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     sim.close()
-    if world_size > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or force_dist()) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     run(args)
 

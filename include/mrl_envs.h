@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MRL_ABI_VERSION 2
+#define MRL_ABI_VERSION 3
 
 /* return codes */
 enum {
@@ -177,7 +177,9 @@ typedef struct mrl_hanabi_config {
  *   world-major with the two agents of a world back to back: one step writes whole
  *   cache lines only.
  *   GAME uint8 (N, 176): the raw per-world game record (tests only; layout in
- *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last step. */
+ *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last completed step (written by
+ *   phase 2); SHARD_COUNT uint32 (1): worlds that finished in the last mrl_step_phase1 -- what the ranks of a
+ *   sharded batch all-gather between the phases (mrl_step_phase2_gathered); mrl_step does not update it. */
 enum {
     MRL_HANABI_DONE = 0,
     MRL_HANABI_ACTIVE_AGENT = 1,
@@ -190,7 +192,8 @@ enum {
     MRL_HANABI_STATE = 8,
     MRL_HANABI_GAME = 9,
     MRL_HANABI_RESET_COUNT = 10,
-    MRL_HANABI_SCAN_TIMEOUT = 11 /* uint32 (1): see mrl_step */
+    MRL_HANABI_SCAN_TIMEOUT = 11, /* uint32 (1): see mrl_step */
+    MRL_HANABI_SHARD_COUNT = 12
 };
 
 int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out);
@@ -202,7 +205,7 @@ int mrl_hanabi_create(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_wor
 /* Slots = ExportID (src/cartpole_env/sim.hpp:17-24); shapes as mgr.cpp:174-202:
  *   RESET int32 (N,1); ACTION int32 (N,1); STATE float32 (N,4) (the Python
  *   binding calls it observation_tensor, bindings.cpp:28); REWARD float32 (N,1);
- *   WORLD_ID int32 (N,1); RESET_COUNT uint32 (1). */
+ *   WORLD_ID int32 (N,1); RESET_COUNT uint32 (1); SHARD_COUNT uint32 (1) (both as for Hanabi). */
 enum {
     MRL_CARTPOLE_RESET = 0,
     MRL_CARTPOLE_ACTION = 1,
@@ -210,7 +213,8 @@ enum {
     MRL_CARTPOLE_REWARD = 3,
     MRL_CARTPOLE_WORLD_ID = 4,
     MRL_CARTPOLE_RESET_COUNT = 5,
-    MRL_CARTPOLE_SCAN_TIMEOUT = 6 /* uint32 (1): see mrl_step */
+    MRL_CARTPOLE_SCAN_TIMEOUT = 6, /* uint32 (1): see mrl_step */
+    MRL_CARTPOLE_SHARD_COUNT = 7
 };
 
 int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
@@ -223,7 +227,7 @@ int mrl_cartpole_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
  *   DONE int32 (N); ACTIVE_AGENT int32 (2,N) all ones; ACTION int32 (2,N,1), values 0..3 = moves -2,-1,+1,+2;
  *   OBSERVATION int32 (2,N,7) = own position history x[0..2], partner's x[3..5] (positions + 2), steps left;
  *   ACTION_MASK int32 (2,N,4) all ones; REWARD float32 (2,N); WORLD_ID / AGENT_ID int32 (2,N);
- *   RESET_COUNT uint32 (1).  The observation IS the world state (sim.cpp:99-112).  Episodes are numbered
+ *   RESET_COUNT uint32 (1); SHARD_COUNT uint32 (1) (both as for Hanabi).  The observation IS the world state (sim.cpp:99-112).  Episodes are numbered
  *   in ascending world order like Cartpole's; mrl_step = phase 1 + phase 2. */
 enum {
     MRL_BALANCE_DONE = 0,
@@ -234,7 +238,8 @@ enum {
     MRL_BALANCE_REWARD = 5,
     MRL_BALANCE_WORLD_ID = 6,
     MRL_BALANCE_AGENT_ID = 7,
-    MRL_BALANCE_RESET_COUNT = 8
+    MRL_BALANCE_RESET_COUNT = 8,
+    MRL_BALANCE_SHARD_COUNT = 9
 };
 
 /* replaces BalanceBeamSimulator(exec_mode=CUDA, gpu_id, num_worlds) (src/balance_beam_env/bindings.cpp:10-24) */
@@ -285,7 +290,8 @@ int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hi
  * Cartpole draw each new episode's seed from one global counter,
  * src/hanabi_env/sim.cpp:449-451, src/cartpole_env/sim.cpp:51-53):
  *   phase 1 = transition + termination test, leaves the number of finishing
- *             worlds in RESET_COUNT;
+ *             worlds of this shard in SHARD_COUNT (a one-workgroup launch behind the
+ *             step kernel that adds up its per-workgroup counts);
  *   phase 2 = re-seed and reset the finishing worlds, taking episode indices
  *             episode_base, episode_base+1, ... in ascending world order.
  * episode_base_dev is a device pointer to one uint32 (the caller computes it
@@ -295,6 +301,14 @@ int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hi
  * phase 1 is the whole step and phase 2 is a no-op. */
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream);
 int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_stream);
+
+/* Phase 2 for rank `rank` of `num_ranks` (1..1024) with the exchange left on the device: counts_dev holds the
+ * SHARD_COUNT word of every rank for this step, in rank order -- exactly what one all-gather of the SHARD_COUNT
+ * tensors delivers.  The re-seeding launch itself adds the lower ranks' counts to the simulator's own episode
+ * counter to get its base and advances that counter by the sum over all ranks, so a sharded step is
+ * phase 1 -> all-gather of one word per rank -> this call, with no other device work in between and no host
+ * sync.  The counter must have been set by mrl_reseed_shard.  No-op for games without an episode counter. */
+int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t num_ranks, uint32_t rank, void *hip_stream);
 
 /* Sets the simulator's own episode counter (next index handed out). Sharded
  * runs call it once after create with the global world offset semantics the

@@ -14,7 +14,7 @@ import subprocess
 import torch  # noqa: F401
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# MRL_ENVS_LIB: load another build of the same ABI (the diagnostic build of `make diag`)
+# MRL_ENVS_LIB: load another build of the same ABI (the diagnostic build of `make diag`, diag/libmrl_envs_diag.so)
 LIB_PATH = os.environ.get("MRL_ENVS_LIB") or os.path.join(_PKG, "libmrl_envs.so")
 CSRC = os.path.join(_PKG, "csrc")
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "mrl_envs.h")
@@ -30,8 +30,9 @@ SYMBOLS = [
     "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
     "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
+    "mrl_step_phase2_gathered",
 ]
-ABI_VERSION = 2  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
+ABI_VERSION = 3  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
 
 class TensorDesc(ctypes.Structure):
@@ -63,7 +64,8 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
-    proc = subprocess.run(["make", "-C", CSRC, "-B"], capture_output=True, text=True)
+    jobs = str(min(6, os.cpu_count() or 1))  # one object per kernel file (csrc/Makefile)
+    proc = subprocess.run(["make", "-C", CSRC, "-j", jobs] + (["-B"] if force else []), capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout + proc.stderr)
     if proc.returncode != 0:
@@ -95,6 +97,7 @@ def lib():
     L.mrl_step_with_actions_i64.argtypes = [vp, vp, vp]
     L.mrl_step_phase1.argtypes = [vp, vp, vp]
     L.mrl_step_phase2.argtypes = [vp, vp, vp]
+    L.mrl_step_phase2_gathered.argtypes = [vp, vp, u32, u32, vp]
     L.mrl_set_episode_counter.argtypes = [vp, u32, vp]
     L.mrl_reseed_shard.argtypes = [vp, u32, u32, vp]
     L.mrl_rollout_random.argtypes = [vp, u32, ctypes.c_uint64, u32, vp]

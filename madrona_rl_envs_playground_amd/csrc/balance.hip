@@ -167,7 +167,8 @@ template <bool kAll>
 __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t chunk, const unsigned long long *__restrict__ finished_mask,
                                                             int32_t *__restrict__ obs, const uint32_t *__restrict__ block_counts,
                                                             const uint32_t *__restrict__ episode_base, uint32_t world_offset,
-                                                            uint32_t *__restrict__ next_counter, uint32_t *__restrict__ reset_count)
+                                                            uint32_t *__restrict__ next_counter, uint32_t *__restrict__ reset_count,
+                                                            const mrl::GatheredCounts gathered)
 {
     __shared__ uint32_t s_red[2 * kBlock / 64];
     __shared__ unsigned long long s_word[kTripWords];
@@ -192,7 +193,9 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t
     if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     uint32_t grand_total = 0;
     uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
-    const uint32_t base = *episode_base;
+    uint32_t base = *episode_base, all_ranks = grand_total;
+    const uint32_t counter_now = base;
+    if (gathered.counts) base += mrl::lower_ranks(gathered, &all_ranks);  // sharded batch: the ranks below come first
     // finished worlds of a trip are compacted into s_list in ascending world order (entry e is the e-th finished
     // world: episode base + running + e), then re-seeded one per thread on dense lanes
     for (uint32_t w0 = 0; w0 < words; w0 += kTripWords) {  // uniform trip count
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t
     }
     if (last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
-        *next_counter = base + grand_total;
+        *next_counter = gathered.counts ? counter_now + all_ranks : base + grand_total;
     }
 }
 
@@ -249,6 +252,7 @@ struct BalanceSim final : mrl_sim {
     int32_t *action = nullptr, *obs = nullptr, *done = nullptr, *world_id = nullptr, *agent_id = nullptr, *active = nullptr, *mask = nullptr;
     float *reward = nullptr;
     uint32_t *block_counts = nullptr, *counter = nullptr, *reset_count = nullptr;
+    uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
 
     void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
@@ -258,13 +262,25 @@ struct BalanceSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
     void phase1(const int32_t *actions, hipStream_t stream) override { launch_step(actions, nullptr, 0, 0, stream); }
-    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
     {
-        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
         hipLaunchKernelGGL((mrl_balance_reset<false>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, base,
-                           0u, counter + (parity ^ 1u), reset_count);
+                           0u, counter + (parity ^ 1u), reset_count, gathered);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+    void publish_shard_count(hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count);
+        MRL_HIP(hipGetLastError());
+    }
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+    }
+    void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
+    {
+        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
     }
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
@@ -283,7 +299,7 @@ struct BalanceSim final : mrl_sim {
         const uint32_t *none = nullptr;
         uint32_t *no_out = nullptr;
         hipLaunchKernelGGL((mrl_balance_reset<true>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, none,
-                           world_offset, no_out, no_out);
+                           world_offset, no_out, no_out, mrl::GatheredCounts{});
         MRL_HIP(hipGetLastError());
         MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
         MRL_HIP(hipMemsetAsync(reward, 0, sizeof(float) * 2 * num_worlds, stream));
@@ -303,6 +319,7 @@ struct BalanceSim final : mrl_sim {
         case MRL_BALANCE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {2, N}); return true;
         case MRL_BALANCE_AGENT_ID: *out = mrl::make_desc(agent_id, MRL_INT32, device, {2, N}); return true;
         case MRL_BALANCE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
+        case MRL_BALANCE_SHARD_COUNT: *out = mrl::make_desc(shard_count, MRL_UINT32, device, {1}); return true;
         default: return false;
         }
     }
@@ -349,6 +366,7 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
         sim->finished_mask = sim->arena.alloc<unsigned long long>(((size_t)sim->grid * sim->chunk + 63) / 64);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        sim->shard_count = sim->arena.alloc<uint32_t>(1);
         hipLaunchKernelGGL(fill_balance_ids, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, 0, sim->world_id, sim->agent_id, sim->active,
                            sim->mask, num_worlds);
         MRL_HIP(hipGetLastError());

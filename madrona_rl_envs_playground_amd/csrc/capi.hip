@@ -116,6 +116,25 @@ static int need_healthy(const mrl_sim *sim)
     return MRL_OK;
 }
 
+// Hanabi, Cartpole and the balance beam keep launch-to-launch state on the HOST (which half of the double-buffered episode
+// counter is current, the epoch tag and the ticket base of the single-launch step): their launches bake it into kernel
+// arguments, so a captured launch replayed later would run with stale values (workgroup indices past the grid, repeated
+// episode seeds).  Refuse to be captured instead of corrupting memory on replay.  Overcooked and Simplecooked have no such
+// state and may be captured (tests/test_gpu_overcooked.py::test_steps_captured_in_a_hip_graph_equal_eager_steps).
+static int need_not_capturing(const mrl_sim *sim, void *hip_stream, const char *what)
+{
+    if (sim->game == MRL_GAME_OVERCOOKED || sim->game == MRL_GAME_SIMPLECOOKED || !hip_stream) return MRL_OK;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)hip_stream, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return MRL_OK;
+    }
+    if (status == hipStreamCaptureStatusNone) return MRL_OK;
+    set_error("%s: this game's launches depend on host-side episode-counter state and cannot be captured in a HIP graph "
+              "(only Overcooked and Simplecooked steps can); issue it outside the capture", what);
+    return MRL_ERR_INVALID;
+}
+
 // ---- roofline.peak_measured of bench.py: float4 streams over caller buffers ----
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int kMode>
@@ -202,6 +221,7 @@ int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out)
 int mrl_step(mrl_sim *sim, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step")) return rc;
     mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->step(nullptr, (hipStream_t)hip_stream); });
 }
@@ -209,6 +229,7 @@ int mrl_step(mrl_sim *sim, void *hip_stream)
 int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_with_actions")) return rc;
     mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->step(actions_dev, (hipStream_t)hip_stream); });
 }
@@ -234,15 +255,32 @@ int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hi
 int mrl_step_phase1(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_phase1")) return rc;
     mrl::DeviceGuard on(sim->device);
-    return guarded([&] { sim->phase1(actions_dev_or_null, (hipStream_t)hip_stream); });
+    return guarded([&] {
+        sim->phase1(actions_dev_or_null, (hipStream_t)hip_stream);
+        sim->publish_shard_count((hipStream_t)hip_stream);
+    });
 }
 
 int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_phase2")) return rc;
     mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->phase2(episode_base_dev, (hipStream_t)hip_stream); });
+}
+
+int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t num_ranks, uint32_t rank, void *hip_stream)
+{
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_phase2_gathered")) return rc;
+    if (!counts_dev || num_ranks == 0 || num_ranks > 1024 || rank >= num_ranks) {
+        mrl::set_error("mrl_step_phase2_gathered: need the gathered counts, 1..1024 ranks and rank < num_ranks (got %u of %u)", rank, num_ranks);
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(sim->device);
+    return guarded([&] { sim->phase2_gathered(counts_dev, num_ranks, rank, (hipStream_t)hip_stream); });
 }
 
 int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream)
@@ -262,6 +300,7 @@ int mrl_reseed_shard(mrl_sim *sim, uint32_t world_offset, uint32_t num_worlds_to
 int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_steps, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_sequence")) return rc;
     mrl::DeviceGuard on(sim->device);
     if (!actions_dev && num_steps) {
         mrl::set_error("mrl_step_sequence: null action array");
@@ -273,6 +312,7 @@ int mrl_step_sequence(mrl_sim *sim, const int32_t *actions_dev, uint32_t num_ste
 int mrl_rollout_random(mrl_sim *sim, uint32_t num_steps, uint64_t seed, uint32_t first_step, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_rollout_random")) return rc;
     mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->rollout_random(num_steps, seed, first_step, (hipStream_t)hip_stream); });
 }

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
                                                              const unsigned long long *__restrict__ finished_mask,
                                                              const uint32_t *__restrict__ episode_base,
                                                              uint32_t *__restrict__ next_counter,
-                                                             uint32_t *__restrict__ reset_count)
+                                                             uint32_t *__restrict__ reset_count, const mrl::GatheredCounts gathered)
 {
     __shared__ uint32_t s_red[2 * kBlock / 64];
     __shared__ unsigned long long s_word[kTripWords];
@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
     if (mine == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
     uint32_t grand_total = 0;
     uint32_t running = mrl::scan_prefix(block_counts, gridDim.x, blockIdx.x, s_red, last_block, &grand_total);
-    const uint32_t base = *episode_base;
+    uint32_t base = *episode_base, all_ranks = grand_total;
+    const uint32_t counter_now = base;
+    if (gathered.counts) base += mrl::lower_ranks(gathered, &all_ranks);  // sharded batch: the ranks below come first
     for (uint32_t w0 = 0; w0 < words; w0 += kTripWords) {  // uniform trip count
         const uint32_t here = min(words - w0, kTripWords);
         if (wave == 0) {
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
     }
     if (last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
-        *next_counter = base + grand_total;
+        *next_counter = gathered.counts ? counter_now + all_ranks : base + grand_total;
     }
 }
 
@@ -443,6 +445,7 @@ struct CartpoleSim final : mrl_sim {
     uint32_t chunk = 0;  // worlds per workgroup
     uint32_t *counter = nullptr;  // [2]: double-buffered episode counter, [parity] is current
     uint32_t *reset_count = nullptr;
+    uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     uint32_t parity = 0;
     // single-launch step (see mrl_cartpole_step_fused)
     unsigned long long *status = nullptr;
@@ -518,13 +521,25 @@ struct CartpoleSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
 
-    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
     {
-        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
         hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, state, block_counts,
-                           finished_mask, base, counter + (parity ^ 1u), reset_count);
+                           finished_mask, base, counter + (parity ^ 1u), reset_count, gathered);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+    void publish_shard_count(hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count);
+        MRL_HIP(hipGetLastError());
+    }
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+    }
+    void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
+    {
+        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
     }
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
@@ -554,6 +569,7 @@ struct CartpoleSim final : mrl_sim {
         case MRL_CARTPOLE_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {N, 1}); return true;
         case MRL_CARTPOLE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
         case MRL_CARTPOLE_SCAN_TIMEOUT: *out = mrl::make_desc(alarm.alarm().dev, MRL_UINT32, device, {1}); return true;
+        case MRL_CARTPOLE_SHARD_COUNT: *out = mrl::make_desc(shard_count, MRL_UINT32, device, {1}); return true;
         default: return false;
         }
     }
@@ -592,6 +608,7 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->finished_mask = sim->arena.alloc<unsigned long long>(((size_t)sim->grid * sim->chunk + 63) / 64);
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
+        sim->shard_count = sim->arena.alloc<uint32_t>(1);
         {
             const uint32_t blocks = (num_worlds + kUnroll * kBlock - 1) / (kUnroll * kBlock);
             if (blocks <= mrl::kMaxFusedBlocks) {

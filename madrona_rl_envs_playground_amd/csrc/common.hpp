@@ -150,6 +150,12 @@ struct mrl_sim {
     // actions == nullptr -> read the simulator's own ACTION tensor
     virtual void phase1(const int32_t *actions, hipStream_t stream) = 0;
     virtual void phase2(const uint32_t *episode_base_dev, hipStream_t stream) = 0;
+    // phase 2 of a sharded batch: `counts` holds every rank's SHARD_COUNT of this step (all-gathered on the device);
+    // the re-seeding launch sums the lower ranks' itself and advances the simulator's own counter by the sum of all.
+    // Games without an episode counter have nothing to do.
+    virtual void phase2_gathered(const uint32_t *, uint32_t, uint32_t, hipStream_t) {}
+    // mrl_step_phase1 only (mrl_step does not pay for it): the shard's finished worlds of the phase 1 just enqueued -> SHARD_COUNT
+    virtual void publish_shard_count(hipStream_t) {}
     // whole step; games whose step is two launches may override it with a single fused launch
     virtual void step(const int32_t *actions, hipStream_t stream)
     {

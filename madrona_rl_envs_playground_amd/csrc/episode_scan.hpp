@@ -31,6 +31,42 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- batches sharded over several GPUs (mrl_step_phase1 / mrl_step_phase2_gathered) ----
+// mrl_step_phase1 leaves the shard's finished worlds in one word (SHARD_COUNT): a one-workgroup launch behind the
+// step kernel adds up its per-workgroup counts.  (One fire-and-forget atomic per workgroup onto that word from the step
+// kernel itself was measured first: 1024 same-address atomics drain at ~8 ns each and the launch cannot end before
+// they have -- Cartpole at 1 M worlds 14.9 -> 22.8 us per step, paid by unsharded runs too.)  Between the phases the
+// ranks all-gather the word, and phase 2 of rank r takes base = own counter + counts of the ranks below r.
+__attribute__((unused)) static __global__ void __launch_bounds__(256) sum_block_counts(const uint32_t *__restrict__ block_counts,
+                                                                                       uint32_t num_blocks, uint32_t *__restrict__ shard_count)
+{
+    __shared__ uint32_t s_wave[4];
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < num_blocks; i += 256) mine += block_counts[i];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) *shard_count = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+struct GatheredCounts {
+    const uint32_t *counts = nullptr;  // nullptr: not a gathered phase 2
+    uint32_t num_ranks = 0, rank = 0;
+};
+
+// finished worlds of the ranks below this one (uniform scalar loads); *all = of every rank
+__device__ __forceinline__ uint32_t lower_ranks(const GatheredCounts &g, uint32_t *all)
+{
+    uint32_t below = 0, total = 0;
+    for (uint32_t r = 0; r < g.num_ranks; r++) {
+        const uint32_t v = g.counts[r];
+        below += r < g.rank ? v : 0u;
+        total += v;
+    }
+    *all = total;
+    return below;
+}
+
 // whole workgroup (blockDim.x a multiple of 64, <= 1024): exclusive prefix of workgroup `block`;
 // with want_total also the sum over all workgroups.  s_red: 2 * blockDim.x / 64 words of LDS.
 __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, uint32_t num_blocks, uint32_t block,

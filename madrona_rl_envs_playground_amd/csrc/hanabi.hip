@@ -102,6 +102,7 @@ struct HanabiParams {
     int32_t *done;       // N
     const int32_t *actions;  // 2 x N
     uint32_t *block_counts;
+    uint32_t *shard_count;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     uint32_t chunk;  // worlds per workgroup (multiple of kWorldsPerBlock)
     // device-side random policy (mrl_rollout_random): sample != 0 -> the mover's action is drawn in the kernel
     uint32_t sample, sample_step;
@@ -1220,7 +1221,7 @@ __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem,
 template <bool kAll, int kV>
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
                                                            uint32_t episode_base_value, uint32_t *next_counter,
-                                                           uint32_t *reset_count)
+                                                           uint32_t *reset_count, const mrl::GatheredCounts gathered)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
@@ -1237,7 +1238,9 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
         p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    const uint32_t base = kAll ? episode_base_value : *episode_base;
+    uint32_t base = kAll ? episode_base_value : *episode_base, all_ranks = 0;
+    const uint32_t counter_now = base;
+    if (!kAll && gathered.counts) base += mrl::lower_ranks(gathered, &all_ranks);  // sharded batch: the ranks below come first
     bool flag = false;
     if (one_sub) {
         const uint32_t local = (threadIdx.x >> 6) * kWorldsPerWave + (threadIdx.x & 63u);
@@ -1250,7 +1253,7 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
     }
     if (!kAll && last_block && threadIdx.x == 0) {
         *reset_count = grand_total;
-        *next_counter = base + grand_total;
+        *next_counter = gathered.counts ? counter_now + all_ranks : base + grand_total;
     }
     reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running, blockIdx.x, one_sub, flag);
 }
@@ -1558,25 +1561,37 @@ struct HanabiSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
 
-    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
     {
-        const uint32_t *base = episode_base_dev ? episode_base_dev : counter + parity;
         switch (variant) {
         case 2:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 2>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count);
+                               counter + (parity ^ 1u), reset_count, gathered);
             break;
         case 1:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 1>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count);
+                               counter + (parity ^ 1u), reset_count, gathered);
             break;
         default:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 0>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count);
+                               counter + (parity ^ 1u), reset_count, gathered);
             break;
         }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+    void publish_shard_count(hipStream_t stream) override
+    {
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, params.block_counts, grid, params.shard_count);
+        MRL_HIP(hipGetLastError());
+    }
+    void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
+    {
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+    }
+    void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
+    {
+        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
     }
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
@@ -1590,9 +1605,9 @@ struct HanabiSim final : mrl_sim {
         const uint32_t *none = nullptr;
         uint32_t *no_out = nullptr;
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_reset<true, 2>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_reset<true, 1>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_reset<true, 2>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_reset<true, 1>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
         }
         MRL_HIP(hipGetLastError());
         set_episode_counter(num_worlds_total, stream);
@@ -1620,6 +1635,7 @@ struct HanabiSim final : mrl_sim {
         case MRL_HANABI_GAME: *out = mrl::make_desc(params.records, MRL_UINT8, device, {N, kRecordBytes}); return true;
         case MRL_HANABI_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
         case MRL_HANABI_SCAN_TIMEOUT: *out = mrl::make_desc(alarm.alarm().dev, MRL_UINT32, device, {1}); return true;
+        case MRL_HANABI_SHARD_COUNT: *out = mrl::make_desc(params.shard_count, MRL_UINT32, device, {1}); return true;
 #ifdef MRL_DIAG
         case 14:
             if (!params.stamps) return false;
@@ -1718,6 +1734,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         a.reward = sim->arena.alloc<float>((size_t)2 * N);
         a.done = sim->arena.alloc<int32_t>(N);
         a.block_counts = sim->arena.alloc<uint32_t>(sim->grid);
+        a.shard_count = sim->arena.alloc<uint32_t>(1);
 #ifdef MRL_DIAG
         a.ablate = (uint32_t)mrl::debug_get("ablate", 0);
         a.stamps = mrl::debug_get("stamps", 0) ? sim->arena.alloc<unsigned long long>((size_t)sim->grid * kWavesPerBlock * 16) : nullptr;

@@ -484,7 +484,7 @@ __device__ __forceinline__ void tick_pots(const StepParams &p, const uint8_t *s_
 {
     tick_pots_world(p, s_pots, s_obj + lane * p.C, lane < nw);
 }
-// Diagnostics (make diag -> libmrl_envs_diag.so, never the shipped library): in-kernel stamps
+// Diagnostics (make diag -> diag/libmrl_envs_diag.so, never the shipped library): in-kernel stamps
 // for tools/stamps.py and phase ablation.  In the normal build these expand to nothing.
 // kPlain: ordinary stores instead of write-through ones.  Write-through wins while the slab fits the 256 MiB Infinity Cache
 // and whenever a group's slab is whole 128-byte lines (cramped_room, counter_circuit); a group slab that is NOT (1300- or

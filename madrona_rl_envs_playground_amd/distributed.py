@@ -16,7 +16,14 @@ collective is needed to *step*.  Two optional exchanges exist:
   src/cartpole_env/sim.cpp:51-53).  To give world ``w`` of a sharded run the same
   episode sequence as in a single-simulator run, ranks all-gather the number of
   worlds that finished in this step (one int32 each) between the two phases of
-  the step; everything stays on the device, nothing synchronises the host.
+  the step; everything stays on the device, nothing synchronises the host.  Phase 1 leaves that
+  number in the simulator's SHARD_COUNT word; the collective gathers the words, and phase 2
+  (``mrl_step_phase2_gathered``) adds up the lower ranks' itself -- a sharded step is two launches
+  and one collective, no torch arithmetic in between.
+
+A process group of ONE rank still runs every collective (RCCL at world_size 1 is how the ``nccl``
+code path is exercised on a one-GPU box, tests/test_gpu_nccl.py); without a process group the
+gathers are identities and no collective is issued.
 """
 import torch
 import torch.distributed as dist
@@ -48,12 +55,12 @@ def gather_worlds(local, world_dim=0, group=None, out=None, sizes=None):
     straight into the output when ``world_dim`` is 0 (RCCL: each rank's slab
     crosses its xGMI links once).  ``sizes`` = per-rank world counts for ragged
     shards (``shard_range`` gives them without communication)."""
-    ws = dist.get_world_size(group) if dist.is_initialized() else 1
-    if ws == 1:
+    if not dist.is_initialized():
         if out is not None:
             out.copy_(local)
             return out
         return local
+    ws = dist.get_world_size(group)
     moved = local.movedim(world_dim, 0).contiguous()
     tail = tuple(moved.shape[1:])
     if sizes is None:
@@ -95,14 +102,9 @@ class ShardedSimulator:
         self.sim = factory(self.n)
         self.needs_episode_exchange = needs_episode_exchange
         if needs_episode_exchange:
-            self.sim.reseed_shard(self.lo, self.total_worlds)
-            done = self._done_flags()
-            self._counter = torch.full((1,), self.total_worlds, dtype=torch.int32, device=done.device)
-            self._counts = torch.zeros((self.world_size,), dtype=torch.int32, device=done.device)
-
-    def _done_flags(self):
-        sim = self.sim
-        return (sim.done_tensor() if hasattr(sim, "done_tensor") else sim.reset_tensor()).to_torch()
+            self.sim.reseed_shard(self.lo, self.total_worlds)  # world i = global world lo + i; the counter starts at total_worlds
+            self._mine = self.sim.shard_count_tensor().to_torch()  # one word, written by phase 1
+            self._counts = torch.zeros((self.world_size,), dtype=self._mine.dtype, device=self._mine.device)
 
     def step(self, actions=None):
         """One step of this rank's worlds.  ``actions``: rank-local action tensor
@@ -114,14 +116,11 @@ class ShardedSimulator:
                 self.sim.step_with_actions(actions)
             return
         self.sim.step_phase1(actions)
-        mine = self._done_flags().sum().to(torch.int32).reshape(1)
-        if self.world_size > 1:
-            _all_gather_into(self._counts, mine, self.group)
-        else:
-            self._counts.copy_(mine)
-        base = self._counter + self._counts[:self.rank].sum().to(torch.int32)
-        self.sim.step_phase2(base)
-        self._counter = self._counter + self._counts.sum().to(torch.int32)
+        if not dist.is_initialized():
+            self.sim.step_phase2(None)  # one shard = the whole batch: the simulator's own counter is the global one
+            return
+        _all_gather_into(self._counts, self._mine, self.group)  # one int32 per rank
+        self.sim.step_phase2_gathered(self._counts, self.rank)
 
     def close(self):
         """Destroys the rank-local simulator (raises if one of its steps hit SCAN_TIMEOUT)."""

@@ -221,12 +221,29 @@ class _Simulator:
         stream = _stream_ptr(self.gpu_id)
         _lib.check(self._L.mrl_step_phase1(self._handle, ptr, stream))
 
+    def _word_pointer(self, words, count, what):
+        """A caller-owned array of ``count`` 32-bit words the library reads on the device (episode base, gathered
+        shard counts): checked here like the action arrays, the C ABI takes a raw pointer."""
+        if (not isinstance(words, torch.Tensor) or not words.is_cuda or words.device.index != self.gpu_id or
+                words.dtype not in (torch.int32, torch.uint32) or not words.is_contiguous() or words.numel() != count):
+            raise ValueError(f"{what} must be a contiguous int32 tensor of {count} element(s) on cuda:{self.gpu_id}")
+        return words.data_ptr()
+
     def step_phase2(self, episode_base=None):
         """``episode_base``: 1-element int32/uint32 CUDA tensor, or None for the
         simulator's own counter."""
         stream = _stream_ptr(self.gpu_id)
-        ptr = episode_base.data_ptr() if episode_base is not None else None
+        ptr = self._word_pointer(episode_base, 1, "episode_base") if episode_base is not None else None
         _lib.check(self._L.mrl_step_phase2(self._handle, ptr, stream))
+
+    def step_phase2_gathered(self, counts, rank):
+        """Phase 2 of rank ``rank`` of a sharded batch: ``counts`` = every rank's SHARD_COUNT of this step (int32 CUDA
+        tensor, one element per rank, what an all-gather of ``shard_count_tensor()`` delivers).  The re-seeding launch
+        works out its own episode base and advances the simulator's counter (``mrl_step_phase2_gathered``)."""
+        if not isinstance(counts, torch.Tensor):
+            raise ValueError("counts must be a tensor")
+        ptr = self._word_pointer(counts, counts.numel(), "counts")
+        _lib.check(self._L.mrl_step_phase2_gathered(self._handle, ptr, int(counts.numel()), int(rank), _stream_ptr(self.gpu_id)))
 
     @property
     def scan_timed_out(self):
@@ -358,6 +375,7 @@ class HanabiSimulator(_Simulator):
     def game_tensor(self): return self._tensor(9)
     def reset_count_tensor(self): return self._tensor(10)
     def scan_timeout_tensor(self): return self._tensor(11)
+    def shard_count_tensor(self): return self._tensor(12)
 
 
 class CartpoleSimulator(_Simulator):
@@ -375,6 +393,7 @@ class CartpoleSimulator(_Simulator):
     def world_id_tensor(self): return self._tensor(4)
     def reset_count_tensor(self): return self._tensor(5)
     def scan_timeout_tensor(self): return self._tensor(6)
+    def shard_count_tensor(self): return self._tensor(7)
 
 
 class BalanceBeamSimulator(_Simulator):
@@ -395,6 +414,7 @@ class BalanceBeamSimulator(_Simulator):
     def world_id_tensor(self): return self._tensor(6)
     def agent_id_tensor(self): return self._tensor(7)
     def reset_count_tensor(self): return self._tensor(8)
+    def shard_count_tensor(self): return self._tensor(9)
 
 
 def random_balance_action(seed, step, world, player):

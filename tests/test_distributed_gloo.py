@@ -34,13 +34,16 @@ class _T:
 
 class FakeEpisodeSim:
     """World w finishes at step t iff hash(global id, t) % 5 == 0; finished worlds
-    get episode numbers in ascending world order from the base given to phase 2."""
+    get episode numbers in ascending world order.  Follows the two-phase protocol of
+    include/mrl_envs.h: phase 1 leaves the shard's finished count in SHARD_COUNT,
+    phase 2 (plain or gathered) hands out the episode numbers."""
 
     def __init__(self, n):
         self.n, self.lo, self.t = n, 0, 0
         self.done = torch.zeros(n, dtype=torch.int32)
         self.episode = torch.arange(n, dtype=torch.int64)
         self.counter = n
+        self.shard_count = torch.zeros(1, dtype=torch.int32)
 
     def reseed_shard(self, lo, total):
         self.lo, self.counter = lo, total
@@ -49,9 +52,13 @@ class FakeEpisodeSim:
     def done_tensor(self):
         return _T(self.done)
 
+    def shard_count_tensor(self):
+        return _T(self.shard_count)
+
     def step_phase1(self, actions=None):
         gid = torch.arange(self.lo, self.lo + self.n)
         self.done = (((gid * 2654435761 + self.t * 40503) >> 3) % 5 == 0).to(torch.int32)
+        self.shard_count.fill_(int(self.done.sum()))  # in place: the exported word never moves
         self.t += 1
 
     def step_phase2(self, base=None):
@@ -59,6 +66,13 @@ class FakeEpisodeSim:
         idx = torch.nonzero(self.done).flatten()
         self.episode[idx] = b + torch.arange(len(idx))
         self.counter = b + len(idx)
+
+    def step_phase2_gathered(self, counts, rank):
+        assert counts.dtype == torch.int32 and int(counts[rank]) == int(self.shard_count)
+        b = self.counter + int(counts[:rank].sum())
+        idx = torch.nonzero(self.done).flatten()
+        self.episode[idx] = b + torch.arange(len(idx))
+        self.counter += int(counts.sum())
 
     def step(self):
         self.step_phase1()

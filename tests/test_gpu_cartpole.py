@@ -217,6 +217,34 @@ def test_scan_timeout_is_an_error_not_a_silent_flag(hip_lib):
     ok.close()
 
 
+def test_step_refuses_graph_capture(hip_lib):
+    """Cartpole / Hanabi / balance launches carry host-side counter state in their arguments: a replayed
+    capture would run with stale values, so the entry points refuse a capturing stream instead (MRL_ERR_INVALID)."""
+    from madrona_rl_envs_playground_amd._lib import MrlError
+    sim = make(2048)
+    a = torch.zeros((2048, 1), dtype=torch.int32, device="cuda")
+    sim.step_with_actions(a)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    refused = 0
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for call in (sim.step, lambda: sim.step_with_actions(a), lambda: sim.step_phase1(a), sim.step_phase2,
+                         lambda: sim.rollout_random(2, seed=3)):
+                try:
+                    call()
+                except MrlError as e:
+                    assert "captured" in str(e)
+                    refused += 1
+            a.add_(0)  # the capture itself stays valid: something was recorded
+    assert refused == 5
+    sim.step_with_actions(a)  # and the simulator is still usable outside the capture
+    torch.cuda.synchronize()
+    assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
+    sim.close()
+
+
 def test_action_arrays_are_validated_on_every_entry_point(hip_lib):
     sim = make(512)
     good = torch.zeros((512, 1), dtype=torch.int32, device="cuda")

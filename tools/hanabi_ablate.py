@@ -3,7 +3,7 @@ action/encode, 2 = no row stores).  Worlds are first advanced 30 legal steps wit
 semantics of the given build, so ablated runs measure timing only."""
 import os, sys, torch
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import _lib
 _lib.debug_set("ablate", int(os.environ.get("MRL_ABLATE", "0")))  # the tool's own command-line knob

@@ -2,7 +2,7 @@
 Prints how a workgroup's four waves spread over the SIMDs of its CU and which workgroups share a CU."""
 import os, sys, collections, torch, numpy as np
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import layouts, _lib
 _lib.debug_set("stamps", 1)

@@ -3,7 +3,7 @@ MRL_ABLATE bits: 1 = no row assembly, 2 = no HBM stores, 4 = no transition, 8 = 
 import os, sys, json, torch
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.environ.get("MRL_ABLATE"):
-    os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+    os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import layouts, _lib
 if os.environ.get("MRL_ABLATE"):

@@ -2,7 +2,7 @@
 2 = encode without the HBM stores, 8 = no encode).  Timing only -- ablated runs compute garbage."""
 import os, sys, torch
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import layouts
 from madrona_rl_envs_playground_amd import _lib

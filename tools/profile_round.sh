@@ -35,7 +35,7 @@ python tools/mappo_rollout_loop.py > $out/${tag}_mappo_rollout_loop.json
 python tools/host_overhead.py 32 > $out/${tag}_host_overhead.txt 2>&1
 python tools/fused_crossover.py > $out/${tag}_fused_crossover.txt 2>&1
 python tools/graph_probe.py > $out/${tag}_graph_probe.txt 2>&1
-MRL_ENVS_LIB=$root/madrona_rl_envs_playground_amd/libmrl_envs_diag.so python tools/graph_probe.py --ablate 16,32,8,4,2,0 >> $out/${tag}_graph_probe.txt 2>&1
+MRL_ENVS_LIB=$root/madrona_rl_envs_playground_amd/diag/libmrl_envs_diag.so python tools/graph_probe.py --ablate 16,32,8,4,2,0 >> $out/${tag}_graph_probe.txt 2>&1
 for l in simple unident_s random0 random3; do python tools/quick_perf_simple.py $l 32768; done > $out/${tag}_simplecooked.txt 2>&1
 timeout -k 10 600 python tools/soak_overcooked.py 6000 > $out/${tag}_soak_overcooked.txt 2>&1
 echo "all done"

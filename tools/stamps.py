@@ -1,7 +1,7 @@
 import os, sys, torch, numpy as np
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # needs the diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag
-os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madrona_rl_envs_playground_amd import layouts
 from madrona_rl_envs_playground_amd import _lib

@@ -1,7 +1,7 @@
 """Per-wave phase timeline of mrl_hanabi_step (diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag)."""
 import os, sys, torch, numpy as np
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "libmrl_envs_diag.so"))
+os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import _lib
 _lib.debug_set("stamps", 1)
