@@ -251,15 +251,16 @@ int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
 
 /* One environment step for every world: replaces Manager::step.
  * Hanabi, Cartpole and the balance beam number new episodes in ascending world order, which
- * takes a prefix sum over the worlds that finished.  For all but small batches mrl_step is two
- * launches (phase 1, phase 2: the kernel boundary is the grid-wide hand-off, nothing waits inside
- * a kernel).  Two kinds of launch DO wait for other workgroups inside the kernel: the
- * single-launch step -- each workgroup takes a ticket (one atomic increment) as its index and
- * waits only for lower tickets, i.e. workgroups known to have started (csrc/episode_scan.hpp);
- * the tickets serialise, so it is the default only where the host's launch rate is the bound
- * (Cartpole up to 1024 worlds, Hanabi up to 10000; mrl_debug_set("fused_step") 1 / 2 forces one /
- * two launches) -- and the persistent multi-step launches of mrl_rollout_random, which need all
- * their workgroups resident and are therefore launched cooperatively.  Every such wait is
+ * takes a prefix sum over the worlds that finished.  Where the kernel exists (Cartpole up to 4 M
+ * worlds, Hanabi up to 262144) mrl_step is ONE launch: every workgroup publishes its count of
+ * finishing worlds and one of its waves looks back at the lower workgroups' counts while the others
+ * already stream out results.  The look-back never depends on another workgroup making progress: a
+ * count that has not appeared after a short bounded wait is recounted by the waiting wave from that
+ * workgroup's inputs (csrc/episode_scan.hpp), so no dispatch order or co-residency is assumed.
+ * Otherwise, for the sharded path and under mrl_debug_set("fused_step", 2), it is two launches
+ * (phase 1, phase 2: the kernel boundary is the grid-wide hand-off).  The persistent multi-step
+ * launches of mrl_rollout_random DO wait for other workgroups inside the kernel; they need all
+ * their workgroups resident and are therefore launched cooperatively.  Those waits are
  * bounded; if one ever expired the SCAN_TIMEOUT tensor of the game becomes nonzero, the
  * episode numbers from that step on are unspecified, and every later mrl_step* /
  * mrl_rollout_random on the simulator returns MRL_ERR_DEVICE (the host learns it from a
@@ -363,8 +364,8 @@ void mrl_destroy(mrl_sim *sim);
  * variable).  Keys (the list with their meanings: csrc/capi.hip, kDebugKeys): overcooked.wpw, overcooked.whole_max,
  * overcooked.lds_max, overcooked.no_share, overcooked.no_fixed, overcooked.no_direct, overcooked.groups,
  * overcooked.whole_store, overcooked.store_policy, overcooked.wide_rollout, overcooked.variant, hanabi.variant,
- * hanabi.no_persistent, cartpole.no_persistent, fused_step (0 by batch size, 1 one launch, 2 two launches),
- * inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
+ * hanabi.no_persistent, cartpole.no_persistent, fused_step (0 the library's choice, 1 one launch, 2 two launches),
+ * fused_heal_test, inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
  * No reference counterpart (the reference has MADRONA_* environment variables for its JIT cache only). */
 int mrl_debug_set(const char *key, int64_t value);
 

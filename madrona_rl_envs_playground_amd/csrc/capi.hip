@@ -33,8 +33,10 @@ static const char *const kDebugKeys[] = {
     "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
-    "fused_step",            // mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel ticketed prefix (episode_scan.hpp) or as
-                             // phase 1 + phase 2 launches: 0 by batch size (one launch for small batches), 1 always one, 2 always two
+    "fused_step",            // mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel look-back (episode_scan.hpp) or as
+                             // phase 1 + phase 2 launches: 0 the library's choice, 1 one launch where the kernel exists, 2 always two
+    "fused_heal_test",       // m > 0: in the single-launch step, workgroups whose index is a multiple of m act as if dispatched late, so
+                             // that higher workgroups take the recount path of the healing look-back (tests)
     "inject_scan_timeout",   // 1: the simulator's SCAN_TIMEOUT alarm is raised right after construction (tests of the error path)
     "ablate",                // diagnostic build only: phase ablation mask
     "stamps",                // diagnostic build only: in-kernel time stamps

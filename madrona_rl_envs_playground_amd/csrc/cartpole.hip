@@ -25,10 +25,6 @@
 namespace {
 
 constexpr int kBlock = 256;
-// mrl_step as ONE launch (ticketed in-kernel prefix) up to this many worlds, as two launches above: a small batch is bound
-// by the host's launch rate (~4.5 us per launch), a large one by the tickets' serialisation (tools/fused_crossover.py, us per
-// step one / two launches: 32 worlds 4.2 / 7.1, 1000 6.8 / 7.0, 10000 8.1 / 5.8, 1 M 28.5 / 14.3)
-constexpr uint32_t kFusedStepMaxWorlds = 1024;
 
 #define GRAVITY 9.8
 #define MASSCART 1.0
@@ -230,28 +226,50 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
     }
 }
 
+// How many of workgroup j's worlds finish in this step, worked out by ONE wave of another workgroup from j's inputs in
+// HBM: what the healing look-back of the single-launch step calls for a workgroup whose own count has not appeared
+// (episode_scan.hpp).  Inlined: a call would give the kernel a stack in scratch memory.  It never runs on an idle GPU.
+__device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *action, const float4 *state, uint32_t j,
+                                                             bool sampled, uint64_t sample_seed, uint32_t sample_step)
+{
+    constexpr uint32_t kChunk = kUnroll * kBlock;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = j * kChunk, last = min(n, first + kChunk);
+    uint32_t count = 0;
+    for (uint32_t i0 = first; i0 < last; i0 += 64u) {
+        const uint32_t i = i0 + lane, ic = i < last ? i : first;
+        float4 s = state[ic];
+        const int32_t a = sampled ? (int32_t)(mrl::policy_hash(sample_seed, sample_step, ic, 0) >> 31) : action[ic];
+        const bool over = i < last && advance(s, a);
+        count += (uint32_t)__popcll(__ballot(over));
+    }
+    return count;
+}
+
 // The whole step in one launch (mrl_step / mrl_step_with_actions on one GPU): workgroup b owns
 // worlds [1024 b, 1024 b + 1024), four per thread, all in registers from the first load to the
-// last store.  Finished worlds get their episode index from the single-launch prefix protocol
-// of episode_scan.hpp and are written once, already re-seeded; the two-launch pair above stays
-// for the sharded path, whose episode base comes from the other ranks between the phases.
+// last store.  Finished worlds get their episode index from the single-launch look-back of
+// episode_scan.hpp (a count that does not appear is recounted from that workgroup's inputs: no
+// workgroup ever depends on another one making progress) and are written once, already re-seeded;
+// the two-launch pair above stays for the sharded path, whose episode base comes from the other
+// ranks between the phases.  A workgroup stores its worlds' state only after its count is globally
+// visible (the __syncthreads behind the publication waits for it).
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *__restrict__ action,
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
                                                                   int32_t *__restrict__ done, unsigned long long *status,
                                                                   uint32_t epoch, const uint32_t *__restrict__ episode_base,
                                                                   uint32_t *__restrict__ next_counter,
-                                                                  uint32_t *__restrict__ reset_count, const mrl::Alarm timed_out,
+                                                                  uint32_t *__restrict__ reset_count,
                                                                   int32_t *action_out, uint64_t sample_seed, uint32_t sample_step,
-                                                                  uint32_t *ticket, uint32_t ticket_base)
+                                                                  const mrl::HealTest heal)
 {
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_red[2 * kBlock / 64];
-    __shared__ uint32_t s_ticket;
-    // the workgroup's index is a ticket, not blockIdx.x: see episode_scan.hpp
-    const uint32_t b = mrl::take_ticket(ticket, ticket_base, &s_ticket);
+    __shared__ uint32_t s_prefix;
+    const uint32_t b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
     const bool last_block = b == gridDim.x - 1;
+    mrl::heal_test_delay(heal, b, gridDim.x, epoch);  // test hook only (uniform branch on a kernel argument)
     float4 s[kUnroll];
     int32_t a[kUnroll];
     const uint32_t base = *episode_base;
@@ -281,8 +299,16 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     uint32_t block_total = 0;
     for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
     if (threadIdx.x == 0) mrl::publish_count(status, b, epoch, block_total);
-    __syncthreads();  // s_wave is reused below
-    // everything that does not need the prefix goes out while the other workgroups publish
+    __syncthreads();  // the count is globally visible (vmcnt(0) in front of the barrier); s_wave is reused below
+    // the first wave looks back BEFORE its own stores (a load would otherwise sit out their acknowledgement) ...
+    if (threadIdx.x < 64 && (block_total != 0 || last_block)) {
+        const bool sampled = action_out != nullptr;
+        const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
+            return recount_chunk(n, action, state, j, sampled, sample_seed, sample_step);
+        });
+        if (threadIdx.x == 0) s_prefix = before;
+    }
+    // ... while everything that does not need the prefix goes out
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
@@ -293,8 +319,9 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
         }
     }
     if (block_total == 0 && !last_block) return;  // uniform per workgroup
-    uint32_t grand_total = 0;
-    uint32_t running = mrl::wait_prefix(status, gridDim.x, b, epoch, s_red, last_block, &grand_total, timed_out);
+    mrl::lds_barrier();
+    uint32_t running = s_prefix;
+    const uint32_t grand_total = running + block_total;  // the whole GPU's, in the last workgroup
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {  // ascending world order: round u covers worlds first + 256 u ...
         uint32_t total;
@@ -450,8 +477,7 @@ struct CartpoleSim final : mrl_sim {
     // single-launch step (see mrl_cartpole_step_fused)
     unsigned long long *status = nullptr;
     mrl::AlarmOwner alarm;
-    uint32_t *ticket = nullptr;    // device: tickets handed out so far (episode_scan.hpp)
-    uint32_t tickets_issued = 0;   // host mirror: fused_grid per fused launch, mod 2^32
+    mrl::HealTest heal;  // test hook of the healing look-back (mrl_debug_set fused_heal_test)
     uint32_t fused_grid = 0, epoch = 0;
     bool scan_timed_out() const override { return alarm.raised(); }
 
@@ -470,10 +496,9 @@ struct CartpoleSim final : mrl_sim {
     {
         epoch += 1;
         hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions, state,
-                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, alarm.alarm(),
-                           action_out, seed, sample_step, ticket, tickets_issued);
+                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed,
+                           sample_step, heal);
         MRL_HIP(hipGetLastError());
-        tickets_issued += fused_grid;
         parity ^= 1u;
     }
 
@@ -618,11 +643,11 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         }
         sim->alarm.init(sim->arena);
         {
-            // mrl_debug_set fused_step: 0 = by batch size, 1 = always one launch, 2 = always two
-            const int64_t knob = mrl::debug_get("fused_step", 0);
-            sim->fused_step = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
+            // mrl_debug_set fused_step: 0 = the library's choice (one launch), 1 = one launch, 2 = always two
+            sim->fused_step = mrl::debug_get("fused_step", 0) != 2;
+            sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
+            sim->heal.seen = sim->arena.alloc<uint32_t>(sim->fused_grid ? sim->fused_grid : 1);
         }
-        sim->ticket = sim->arena.alloc<uint32_t>(1);
         if (sim->fused_grid) {
             int per_cu = 0, cus = 0;
             MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&mrl_cartpole_rollout), kBlock, 0));

@@ -102,43 +102,43 @@ __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, ui
 
 // ---------------------------------------------------------------------------------------------
 // Single-launch variant.  Instead of ending the kernel between "count" and "prefix", every
-// workgroup publishes (epoch, count) in one 64-bit word and then waits until all lower-numbered
-// workgroups have published theirs for the same epoch (the host passes a fresh epoch per launch,
-// so the status words are never cleared).
+// workgroup publishes (epoch, count) in one 64-bit word and then looks back at the words of all
+// lower-numbered workgroups for the same epoch (the host passes a fresh epoch per launch, so the
+// status words are never cleared).
 //
-// Why the wait cannot deadlock, whatever the occupancy, the dispatch order and whatever else runs
-// on the GPU: a workgroup's index in this protocol is NOT blockIdx.x but a TICKET, the value one
-// atomic increment returned when the workgroup started (take_ticket below; the same device rocPRIM's
-// look-back scan uses).  A workgroup that holds ticket t therefore knows that tickets 0..t-1 were
-// handed out before, i.e. those workgroups are running or done.  It publishes before it waits
-// and waits only for lower tickets, so the lowest unfinished ticket never waits for anybody: by
-// induction every wait ends.  HIP promises nothing about dispatch order (MI355X_MICROARCH.md,
-// "Workgroup dispatch"), and nothing here assumes any.  The ticket also decides which worlds the
-// workgroup owns, so "ascending world order" and "ascending ticket" are the same order.
-// The wait is bounded all the same; on expiry the Alarm is raised (the launch then finishes with
-// wrong episode numbers instead of hanging the GPU) and every later call on the simulator fails.
+// Why the look-back cannot deadlock, whatever the occupancy, the dispatch order and whatever else
+// runs on the GPU: it never DEPENDS on another workgroup.  A count that has not appeared after a
+// short bounded wait is RECOMPUTED by the waiting wave from that workgroup's inputs -- the count of
+// finishing worlds is a pure function of the worlds' state and actions before the step
+// (wave_prefix_or_recount below; the game supplies the recount).  HIP promises nothing about
+// dispatch order or co-residency (MI355X_MICROARCH.md, "Workgroup dispatch"), and nothing here
+// assumes any: on an idle GPU all workgroups run side by side and publish within a microsecond of
+// each other, so the recount is never taken; if a lower workgroup has not even started, the
+// waiting one pays for its transition a second time and goes on.
+//
+// For the recount to read PRE-step inputs, a workgroup changes its worlds' state in HBM only after
+// its own count is globally visible (publish, s_waitcnt vmcnt(0), then a flag in LDS the other
+// waves look at before they store), and the healing wave re-reads the status word after the
+// recount: if the count has appeared meanwhile it takes the published one (the inputs it read may
+// have been overwritten), otherwise the inputs it read were still the old ones.
+//
+// (Round 2 made the wait safe with TICKETS instead -- a workgroup's index was the value one
+// returning atomic gave it, so everything it waited for had started.  The 256..1024 atomics on one
+// word serialise at ~11 ns each and every workgroup's first load waits for its ticket: 3 us on the
+// front of a 23 us launch, which made the single launch slower than two.  And a cooperative launch,
+// which does guarantee co-residency, costs 25-30 us per launch on this runtime: tools/coop_probe.py.)
 //
 // The persistent rollouts (mrl_*_rollout) are a different matter: there every workgroup waits for
 // EVERY other one at each step, which needs the whole grid resident at once.  They are launched
 // with hipLaunchCooperativeKernel, which refuses a grid the device cannot hold, and the host falls
-// back to one launch per step when it does.
+// back to one launch per step when it does; their waits are bounded and raise the Alarm on expiry.
 // ---------------------------------------------------------------------------------------------
 // test hook (mrl_debug_set "inject_scan_timeout"): raises the alarm exactly as an expired wait would
 __attribute__((unused)) static __global__ void raise_alarm_kernel(const Alarm alarm) { alarm.raise(); }
 
 constexpr uint32_t kMaxFusedBlocks = 4096;
-constexpr uint32_t kMaxPolls = 1u << 22;  // ~1 s of polling
-
-// One returning atomic per workgroup (thread 0), broadcast through LDS.  `ticket` counts up for
-// the simulator's whole life; `ticket_base` is its value when this launch started (the host
-// knows it: launches of one simulator never overlap and each hands out exactly gridDim.x
-// tickets), so the difference is this workgroup's index in the launch.  Ends with a barrier.
-__device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t ticket_base, uint32_t *s_slot)
-{
-    if (threadIdx.x == 0) *s_slot = atomicAdd(ticket, 1u) - ticket_base;
-    __syncthreads();
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)*s_slot);
-}
+constexpr uint32_t kMaxPolls = 1u << 22;  // ~1 s of polling (persistent rollouts)
+constexpr uint32_t kHealPolls = 96;       // ~100 us: then the single-launch look-back recounts instead of waiting
 
 __device__ __forceinline__ void publish_count(unsigned long long *status, uint32_t block, uint32_t epoch, uint32_t count)
 {
@@ -179,50 +179,76 @@ __device__ __forceinline__ uint32_t read_counts(const unsigned long long *status
     return all;
 }
 
-// whole workgroup; same contract as scan_prefix
-__device__ __forceinline__ uint32_t wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
-                                                uint32_t *s_red, bool want_total, uint32_t *grand_total, const Alarm &timed_out)
+// ---- the self-healing look-back of the single-launch step (one wave) ----
+// Test hook (mrl_debug_set "fused_heal_test" = m > 0): workgroups whose index is a multiple of m (but not the last)
+// behave like a workgroup that was dispatched late -- they do nothing until a higher workgroup has recounted them
+// (heal_seen[index] == epoch) or a bounded wait expires -- so the recount path runs against untouched inputs.
+struct HealTest {
+    uint32_t mod = 0;
+    uint32_t *seen = nullptr;  // one word per workgroup
+};
+
+__device__ __forceinline__ void heal_test_delay(const HealTest &t, uint32_t block, uint32_t num_blocks, uint32_t epoch)
 {
-    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
-    uint32_t before = 0, all = 0;
-    const uint32_t limit = want_total ? num_blocks : block;
-    for (uint32_t first = 0; first < limit; first += nthreads * 4u)
-        all += read_counts<4>(status, first, limit, epoch, block, &before, timed_out, tid, nthreads);
-    for (int off = 32; off > 0; off >>= 1) {
-        before += __shfl_down(before, off, 64);
-        all += __shfl_down(all, off, 64);
+    if (t.mod == 0 || block % t.mod != 0 || block + 1 == num_blocks) return;  // uniform per workgroup
+    if (threadIdx.x == 0) {
+        for (uint32_t polls = 0; polls < (1u << 14); polls++) {
+            if (__hip_atomic_load(&t.seen[block], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
     }
-    const uint32_t nwaves = nthreads >> 6;
-    if ((tid & 63u) == 0) {
-        s_red[tid >> 6] = before;
-        s_red[nwaves + (tid >> 6)] = all;
-    }
-    lds_barrier();
-    uint32_t prefix = 0, total = 0;
-    for (uint32_t w = 0; w < nwaves; w++) {
-        prefix += s_red[w];
-        total += s_red[nwaves + w];
-    }
-    lds_barrier();
-    if (grand_total) *grand_total = total;
-    return prefix;
+    __syncthreads();
 }
 
-// One wave's version of wait_prefix (no workgroup barrier): lets ONE wave of a workgroup do the
-// look-back while the others go on.  A vector load cannot return before the wave's older stores
-// have been acknowledged (loads and stores share vmcnt, in issue order), so the wave that looks
-// back should do so before it streams out its own results.
-__device__ __forceinline__ uint32_t wave_wait_prefix(unsigned long long *status, uint32_t num_blocks, uint32_t block, uint32_t epoch,
-                                                     bool want_total, uint32_t *grand_total, const Alarm &timed_out)
+// Sum of the counts of workgroups [0, block) for `epoch`, to every lane of the calling wave.  recount(i) is called
+// by the WHOLE wave (uniform i) and returns workgroup i's count to every lane.
+template <typename Recount>
+__device__ __forceinline__ uint32_t wave_prefix_or_recount(const unsigned long long *status, uint32_t block, uint32_t epoch,
+                                                           const HealTest &test, Recount &&recount)
 {
-    uint32_t before = 0, all = 0;
-    const uint32_t limit = want_total ? num_blocks : block;
-    for (uint32_t first = 0; first < limit; first += 64u * 8u) all += read_counts<8>(status, first, limit, epoch, block, &before, timed_out);
-    for (int off = 32; off > 0; off >>= 1) {
-        before += __shfl_xor(before, off, 64);
-        all += __shfl_xor(all, off, 64);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t before = 0;
+    for (uint32_t first = 0; first < block; first += 64u * 8u) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t i = first + lane + 64u * j;
+            v[j] = i < block ? __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        // all words that have not appeared are asked for again TOGETHER (one round trip per poll, not one per word:
+        // under the other waves' row stores a round trip is ~2 us)
+        uint32_t missing = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) missing |= (first + lane + 64u * j < block && (uint32_t)(v[j] >> 32) != epoch) ? 1u << j : 0u;
+        for (uint32_t polls = 0; polls < kHealPolls && __ballot(missing != 0) != 0ull; polls++) {
+            __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((missing >> j) & 1u) v[j] = __hip_atomic_load(&status[first + lane + 64u * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)(v[j] >> 32) == epoch) missing &= ~(1u << j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (first + lane + 64u * j < block && !((missing >> j) & 1u)) before += (uint32_t)v[j];
+        if (__ballot(missing != 0) == 0ull) continue;
+        for (int j = 0; j < 8; j++) {
+            unsigned long long todo = __ballot((missing >> j) & 1u);
+            while (todo) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const uint32_t i = first + src + 64u * j;  // wave-uniform
+                uint32_t c = recount(i);
+                // a count that has appeared meanwhile wins: the inputs just read may already have been overwritten
+                const unsigned long long now = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(now >> 32) == epoch) c = (uint32_t)now;
+                if (test.mod && lane == 0) __hip_atomic_store(&test.seen[i], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                before += lane == src ? c : 0u;
+            }
+        }
     }
-    *grand_total = all;
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
     return before;
 }
 

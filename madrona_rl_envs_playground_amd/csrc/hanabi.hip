@@ -48,10 +48,6 @@ constexpr int kWave = 64;
 #endif
 constexpr int kWavesPerBlock = MRL_HANABI_WPB;
 constexpr int kBlock = kWave * kWavesPerBlock;
-// mrl_step as ONE launch (ticketed in-kernel prefix) up to this many worlds, as two launches above: a small batch is bound
-// by the host's launch rate (~4.5 us per launch), a large one by the tickets' serialisation (tools/fused_crossover.py, us per
-// step one / two launches: 32 worlds 15.1 / 15.8, 1000 18.7 / 19.7, 10000 18.7 / 20.0, 16384 20.5 / 20.4, 65536 29.2 / 26.6)
-constexpr uint32_t kFusedStepMaxWorlds = 10000;
 constexpr int kWorldsPerWave = MRL_HANABI_WPW;
 constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
 #ifndef MRL_HANABI_EU
@@ -61,7 +57,6 @@ constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
 constexpr int kHand = 5;
 constexpr int kRecordBytes = 176;
 constexpr int kRecordWords = kRecordBytes / 4;
-static_assert(kRecordWords == 44, "load_records divides by 44 with a multiply-shift");
 constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-record accesses spread over banks
 constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
 // Output rows in HBM: everything one agent of one world receives from a step is ONE 1536-byte
@@ -127,7 +122,19 @@ struct HanabiParams {
             p.stamps[(size_t)(bid * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
     } while (0)
 #define ABLATED(bit) (p.ablate & (bit))
+// the single-launch step: one sub-block per workgroup, stamps of every wave
+#define FSTAMP(k)                                                                                                 \
+    do {                                                                                                          \
+        if (p.stamps && lane == 0) p.stamps[(size_t)(bid * kWavesPerBlock + wib) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// the scan wave (ninth wave, owns no world) leaves its stamps in the unused slots 8.. of the workgroup's first wave
+#define FSTAMP_SCAN(k)                                                                                            \
+    do {                                                                                                          \
+        if (p.stamps && lane == 0) p.stamps[(size_t)(bid * kWavesPerBlock) * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
+#define FSTAMP_SCAN(k) ((void)0)
+#define FSTAMP(k) ((void)0)
 #define STAMP(k) ((void)0)
 #define STAMP_REALTIME(k) ((void)0)
 #define ABLATED(bit) false
@@ -781,6 +788,39 @@ __device__ __forceinline__ void apply_variant(const HanabiParams &p, uint8_t *re
         apply_action<(kV ? 5 : 0)>(p, rec, uid);
 }
 
+// One world's move on its record in LDS: the mover's action (given, or drawn here under mrl_rollout_random), actionSystem
+// (sim.cpp:596-792) and checkDone's score / reward / termination test (sim.cpp:812-850).  Touches nothing but the record
+// unless `publish` (then the drawn action goes to the ACTION tensor): the single-launch step's healing look-back runs it
+// on a scratch copy of another workgroup's worlds to learn how many of them finish.
+struct Moved {
+    bool over;
+    float reward;
+};
+template <int kV>
+__device__ __forceinline__ Moved move_world(const HanabiParams &p, uint8_t *rec, uint32_t world, int32_t act0, int32_t act1, bool publish)
+{
+    constexpr int kR = kV ? 5 : 0;
+    const uint32_t actor = rec[R_CUR] & 1u;
+    uint32_t uid = (uint32_t)(actor ? act1 : act0);
+    if (p.sample) {  // uniform over the mover's legal moves (random_policy.hpp)
+        const uint32_t legal = legal_moves<kR>(p, rec, actor);
+        const uint32_t count = (uint32_t)__popc(legal);
+        uid = count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, actor), count)) : 0u;
+        if (publish) p.action_out[(size_t)actor * p.num_worlds + world] = (int32_t)uid;
+    }
+    apply_variant<kV>(p, rec, uid);
+    const int32_t old_score = (int8_t)rec[R_SCORE];
+    int32_t score = 0;
+    if (rec[R_LIFE] > 0)
+        for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
+    rec[R_SCORE] = (uint8_t)score;
+    rec[R_NEWREW] = (uint8_t)(score - old_score);
+    Moved m;
+    m.reward = (float)(int8_t)(score - old_score);
+    m.over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
+    return m;
+}
+
 // sim.cpp:446-532, without the encode.  The ten opening draws keep the generator and the deck
 // size in registers; the LDS reads of one draw (the drawn card, the deck's last card) do not
 // depend on the previous draw's write being waited for (DS ops execute in order).
@@ -961,23 +1001,65 @@ __device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveL
     }
 }
 
+// The wave's records, HBM <-> LDS.  A wave's worlds are one contiguous run of 176-byte records (32 worlds = 44 whole
+// cache lines), moved 16 bytes per lane and instruction; a record is 11 such chunks, so none straddles two records.
+// Loading comes in two halves so that a kernel can request the records with its first instructions and put them into
+// LDS when it gets there: all global loads are in flight before the first LDS write.
+constexpr int kRecordChunks = kRecordBytes / 16;  // 11
+static_assert(kRecordChunks * 16 == kRecordBytes, "records are whole 16-byte chunks");
+constexpr int kRecordLoadRounds = (kWorldsPerWave * kRecordChunks + kWave - 1) / kWave;  // 6
+struct RecordLoads {
+    uint4 v[kRecordLoadRounds];
+};
+__device__ __forceinline__ void request_records(const uint32_t *records, uint32_t w0, uint32_t nw, uint32_t lane, RecordLoads &r)
+{
+    const uint32_t total = nw * kRecordChunks;
+    const uint4 *src = reinterpret_cast<const uint4 *>(records + (size_t)w0 * kRecordWords);
+#pragma unroll
+    for (int k = 0; k < kRecordLoadRounds; k++) {
+        const uint32_t c = lane + k * kWave;
+        r.v[k] = c < total ? src[c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+__device__ __forceinline__ uint32_t *record_chunk_in_lds(const WaveLds &l, uint32_t c)
+{
+    const uint32_t rec = (c * 745u) >> 13, part = c - rec * kRecordChunks;  // c / 11, exact for c < 2738
+    return reinterpret_cast<uint32_t *>(l.rec + rec * kRecStride + part * 16u);  // 4-byte aligned (the stride is 180)
+}
+__device__ __forceinline__ void place_records(const WaveLds &l, uint32_t nw, uint32_t lane, const RecordLoads &r)
+{
+    const uint32_t total = nw * kRecordChunks;
+#pragma unroll
+    for (int k = 0; k < kRecordLoadRounds; k++) {
+        const uint32_t c = lane + k * kWave;
+        if (c < total) {
+            uint32_t *dst = record_chunk_in_lds(l, c);
+            dst[0] = r.v[k].x;
+            dst[1] = r.v[k].y;
+            dst[2] = r.v[k].z;
+            dst[3] = r.v[k].w;
+        }
+    }
+}
 __device__ __forceinline__ void load_records(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t nw, uint32_t lane)
 {
-    // all global loads of the wave's records are in flight before the first LDS write
-    constexpr int kRounds = (kWorldsPerWave * kRecordWords + kWave - 1) / kWave;
-    const uint32_t total = nw * kRecordWords;
-    const uint32_t *src = p.records + (size_t)w0 * kRecordWords;
-    uint32_t v[kRounds];
+    RecordLoads r;
+    request_records(p.records, w0, nw, lane, r);
+    place_records(l, nw, lane, r);
+}
+
+// all of the wave's records back to HBM: six full-width stores of whole cache lines instead of one 176-byte store per world
+__device__ __forceinline__ void store_records(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t nw, uint32_t lane)
+{
+    const uint32_t total = nw * kRecordChunks;
+    uint4 *dst = reinterpret_cast<uint4 *>(p.records + (size_t)w0 * kRecordWords);
 #pragma unroll
-    for (int k = 0; k < kRounds; k++) {
-        const uint32_t i = lane + k * kWave;
-        v[k] = i < total ? src[i] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kRounds; k++) {
-        const uint32_t i = lane + k * kWave;
-        const uint32_t r = (i * 2979u) >> 17, w = i - r * kRecordWords;  // i / 44, exact for i < 4096
-        if (i < total) reinterpret_cast<uint32_t *>(l.rec + r * kRecStride)[w] = v[k];
+    for (int k = 0; k < kRecordLoadRounds; k++) {
+        const uint32_t c = lane + k * kWave;
+        if (c < total) {
+            const uint32_t *src = record_chunk_in_lds(l, c);
+            dst[c] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
     }
 }
 
@@ -991,19 +1073,9 @@ __device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLd
 // multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
 // The transition of the workgroup's worlds; returns how many of them finished (to every thread).
 // Rows of finished worlds are not written: the reset that follows writes both agents' rows anew.
-// what the single-launch step needs on top of the transition (see mrl_hanabi_step_fused)
-struct FusedScan {
-    unsigned long long *status;
-    uint32_t epoch;
-    uint32_t *s_part;  // LDS: [0] finished worlds before this workgroup, [1] on the whole GPU
-    mrl::Alarm timed_out;
-};
-
-template <int kV, bool kFused>
-__device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, bool *last_over,
-                                              const FusedScan &scan, const uint32_t bid)
+template <int kV>
+__device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *smem, uint32_t *s_counts, const uint32_t bid)
 {
-    constexpr int kR = kV ? 5 : 0;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keeps w0, nw and the row descriptors in SGPRs
     const WaveLds l = wave_lds(smem, wib);
@@ -1032,15 +1104,8 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
             uint8_t *rec = l.rec + lane * kRecStride;
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
-            const uint32_t actor = rec[R_CUR] & 1u;
-            uint32_t uid = (uint32_t)(actor ? act1 : act0);
-            if (p.sample) {  // uniform over the mover's legal moves (random_policy.hpp)
-                const uint32_t legal = legal_moves<kR>(p, rec, actor);
-                const uint32_t count = (uint32_t)__popc(legal);
-                uid = count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, actor), count)) : 0u;
-                p.action_out[(size_t)actor * N + world] = (int32_t)uid;
-            }
-            if (!ABLATED(1)) apply_variant<kV>(p, rec, uid);
+            Moved m{false, 0.f};
+            if (!ABLATED(1)) m = move_world<kV>(p, rec, world, act0, act1, true);
             STAMP(2);
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
@@ -1051,49 +1116,16 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
             // store's data register, 0.4..1 us here -- was measured: 36.0 us per step against 34.5.)
             p.active[(size_t)next * N + world] = 1;
             p.active[(size_t)(next ^ 1u) * N + world] = 0;
-            // checkDone (:812-850)
-            const int32_t old_score = (int8_t)rec[R_SCORE];
-            int32_t score = 0;
-            if (rec[R_LIFE] > 0)
-                for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
-            rec[R_SCORE] = (uint8_t)score;
-            rec[R_NEWREW] = (uint8_t)(score - old_score);
-            const float rew = (float)(int8_t)(score - old_score);
-            p.reward[world] = rew;
-            p.reward[(size_t)N + world] = rew;
-            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
+            p.reward[world] = m.reward;
+            p.reward[(size_t)N + world] = m.reward;
+            over = m.over;
             p.done[world] = over ? 1 : 0;
         }
         const unsigned long long overs = __ballot(over);
         finished += (uint32_t)__popcll(overs);
-        *last_over = over;
         const unsigned long long movers = __ballot(next_is_1);
         wave_lds_sync();
         STAMP(4);
-        if constexpr (kFused) {
-            // The workgroup's count is final once its last sub-block is through phase A: publish
-            // it, and let the last wave look back at the lower workgroups NOW, before its row
-            // stores -- afterwards every load would first sit out the acknowledgement of those
-            // write-through stores (4.6 us measured), and the re-deal below issues no load at all.
-            if (sub + kWorldsPerBlock >= chunk_end) {
-                if (lane == 0) s_counts[wib] = finished;
-                mrl::lds_barrier();
-                if (wib == kWavesPerBlock - 1) {
-                    uint32_t total = 0;
-                    for (int w = 0; w < kWavesPerBlock; w++) total += s_counts[w];
-                    if (lane == 0) mrl::publish_count(scan.status, bid, scan.epoch, total);
-                    const bool last_block = bid == gridDim.x - 1;
-                    if (total != 0 || last_block) {
-                        uint32_t grand = 0;
-                        const uint32_t before = mrl::wave_wait_prefix(scan.status, gridDim.x, bid, scan.epoch, last_block, &grand, scan.timed_out);
-                        if (lane == 0) {
-                            scan.s_part[0] = before;
-                            scan.s_part[1] = grand;
-                        }
-                    }
-                }
-            }
-        }
 
         // phase B: bits -> bytes for every world's player to move; the wave's worlds are one
         // contiguous run of blocks, so a lane's target is a 32-bit offset from a scalar base
@@ -1103,8 +1135,7 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
             if (!ABLATED(2)) expand_movers(p, l, nw, overs, movers, out, lane);
         }
         STAMP(5);
-        for (uint32_t r = 0; r < nw; r++)
-            if (!((overs >> r) & 1ull)) store_record(p, l, w0, r, lane);  // a finished world's record comes from the re-deal
+        store_records(p, l, w0, nw, lane);  // (a finished world's record is dealt anew by the re-deal launch that follows)
         wave_lds_sync();
         STAMP(6);
         STAMP_REALTIME(14);
@@ -1138,8 +1169,7 @@ mrl_hanabi_step(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_
     q.actions = hot_actions;
     q.num_worlds = hot_num_worlds;
     q.chunk = hot_chunk;
-    bool last_over;
-    const uint32_t total = step_body<kV, false>(q, smem, s_counts, &last_over, FusedScan{}, blockIdx.x);
+    const uint32_t total = step_body<kV>(q, smem, s_counts, blockIdx.x);
     if (threadIdx.x == 0) q.block_counts[blockIdx.x] = total;
 }
 
@@ -1258,38 +1288,200 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
     reset_body<kAll, kV>(p, smem, s_counts, s_list, base, running, blockIdx.x, one_sub, flag);
 }
 
-// The whole step in one launch (mrl_step on one GPU): transition, then the single-launch prefix
-// protocol of episode_scan.hpp instead of a kernel boundary, then the re-deal.  The two-launch
-// pair stays for the sharded path, whose episode base comes from the other ranks in between.
+// How many worlds of workgroup j's chunk finish in this step, worked out by ONE wave of another workgroup from j's
+// inputs (records and actions in HBM) on a scratch copy in LDS: what the healing look-back calls for a workgroup whose
+// own count has not appeared (episode_scan.hpp).  Inlined (a call would give the kernel a stack in scratch memory: 39.8 against 30.4 us per step measured); it never runs on an idle GPU.
 template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
-mrl_hanabi_step_fused(const HanabiParams p, unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
-                      uint32_t *next_counter, uint32_t *reset_count, const mrl::Alarm timed_out, uint32_t *ticket, uint32_t ticket_base)
+__device__ __forceinline__ uint32_t recount_chunk(const HanabiParams &p, uint8_t *scratch, uint32_t j)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
-    __shared__ uint32_t s_counts[kWavesPerBlock];
-    __shared__ uint32_t s_part[2 * kWavesPerBlock];
-    __shared__ uint8_t s_list[kWorldsPerBlock];
-    __shared__ uint32_t s_ticket;
-    const uint32_t base = *episode_base;  // requested now, needed after the transition
-    // the workgroup's index is a ticket, not blockIdx.x: see episode_scan.hpp
-    const uint32_t bid = mrl::take_ticket(ticket, ticket_base, &s_ticket);
-    const bool last_block = bid == gridDim.x - 1;
-    bool last_over = false;
-    const uint32_t total = step_body<kV, true>(p, smem, s_counts, &last_over, FusedScan{status, epoch, s_part, timed_out}, bid);
-    if (total == 0 && !last_block) return;  // uniform for the workgroup
-    const uint32_t running = s_part[0], grand_total = s_part[1];  // left by the last wave (barriers inside step_body)
-    if (last_block && threadIdx.x == 0) {
-        *reset_count = grand_total;
-        *next_counter = base + grand_total;
+    const uint32_t lane = threadIdx.x & 63;
+    const WaveLds l{scratch, nullptr};
+    const uint32_t N = p.num_worlds;
+    const uint32_t first = j * p.chunk, end = min(N, first + p.chunk);
+    uint32_t count = 0;
+    for (uint32_t w0 = first; w0 < end; w0 += kWorldsPerWave) {
+        const uint32_t nw = min((uint32_t)kWorldsPerWave, end - w0);
+        int32_t act0 = 0, act1 = 0;
+        if (lane < nw && !p.sample) {
+            act0 = p.actions[w0 + lane];
+            act1 = p.actions[(size_t)N + w0 + lane];
+        }
+        load_records(p, l, w0, nw, lane);
+        wave_lds_sync();
+        bool over = false;
+        if (lane < nw) over = move_world<kV>(p, scratch + lane * kRecStride, w0 + lane, act0, act1, false).over;
+        count += (uint32_t)__popcll(__ballot(over));
+        wave_lds_sync();
     }
-    // No global address is written by both parts (the transition skips the rows and the record of
-    // a finished world), so the re-deal needs no ordering against the transition's stores.
-#ifdef MRL_DIAG
-    if (p.stamps && (threadIdx.x & 63) == 0)
-        p.stamps[(size_t)(bid * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 7] = __builtin_amdgcn_s_memtime();
-#endif
-    reset_body<false, kV>(p, smem, s_counts, s_list, base, running, bid, p.chunk == (uint32_t)kWorldsPerBlock, last_over);
+    return count;
+}
+
+// The whole step in ONE launch (mrl_step on one GPU, batches of one sub-block per workgroup: up to 262144 worlds):
+// transition, look-back over the lower workgroups' finished counts instead of a kernel boundary, re-deal.  Workgroup
+// b owns worlds [256 b, 256 b + 256) and has NINE waves: eight step 32 worlds each exactly like mrl_hanabi_step
+// (phase A lane = world, phase B bits -> bytes), the ninth -- the scan wave -- owns no world.  It sleeps at the barrier
+// behind phase A, then publishes the workgroup's count, looks back (recounting what does not appear,
+// episode_scan.hpp) and deals ALL of the workgroup's finished worlds anew in their slots of the other waves' LDS
+// (record + both agents' bit vectors) while the eight are streaming out their rows; each of them appends the rows
+// of its own finished worlds to its stream of stores.  The serial part of the re-deal (look-back 2 us, ten dependent
+// draws, encode) is in no stepping wave's instruction stream: measured with the re-deal in the stepping waves (the
+// last of them looking back first), that wave started its rows 2 us late and ended the workgroup in 208 of 256 cases,
+// and every wave with a finished world queued 2.8 us of re-deal behind its rows
+// (profiles/r03_e_hanabi_fused_timeline.txt).
+// The two-launch pair stays for the sharded path (the episode base comes from the other ranks in between) and for
+// larger batches.
+constexpr int kFusedBlock = kBlock + kWave;
+
+// (nine waves = three on one of the four SIMDs: amdgpu_waves_per_eu(3) holds the kernel to 168 VGPRs)
+template <int kV>
+__global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_eu(3)))
+mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t heal_mod, const HanabiParams p0,
+                      unsigned long long *status, uint32_t epoch, const uint32_t *episode_base, uint32_t *next_counter,
+                      uint32_t *reset_count, uint32_t *heal_seen)
+{
+    constexpr int kR = kV ? 5 : 0;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_scratch[kWorldsPerWave * kRecStride];  // the scan wave's copy of another workgroup's records (healing)
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_ready;  // 1: the workgroup's count is globally visible, records may be overwritten; 2: the fresh games are in LDS as well
+    __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
+    // the records are requested with the kernel's first instructions, from the preloaded arguments alone
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t bid = blockIdx.x;
+    const bool scan_wave = wib == (uint32_t)kWavesPerBlock;
+    const uint32_t w0 = bid * kWorldsPerBlock + wib * kWorldsPerWave;
+    const uint32_t nw = (!scan_wave && w0 < hot_num_worlds) ? min((uint32_t)kWorldsPerWave, hot_num_worlds - w0) : 0u;
+    RecordLoads pending;
+    request_records(hot_records, w0, nw, lane, pending);
+
+    HanabiParams p = p0;
+    p.records = hot_records;
+    p.actions = hot_actions;
+    p.num_worlds = hot_num_worlds;
+    const mrl::HealTest heal{heal_mod, heal_seen};
+    const uint32_t N = p.num_worlds;
+    const bool last_block = bid == gridDim.x - 1;
+    if (threadIdx.x == 0) s_ready = 0u;
+    if (heal_mod) mrl::heal_test_delay(heal, bid, gridDim.x, epoch);  // test hook only (uniform branch on a preloaded argument)
+
+    if (scan_wave) {
+        // ================= the scan wave =================
+        const uint32_t base = *episode_base;  // requested now, needed after the look-back
+        mrl::lds_barrier();                   // phase A of the eight is through: s_counts and s_fin are there
+        FSTAMP_SCAN(0);
+        uint32_t start_of[kWavesPerBlock + 1];
+        start_of[0] = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; w++) start_of[w + 1] = start_of[w] + s_counts[w];
+        const uint32_t block_total = start_of[kWavesPerBlock];
+        if (lane == 0) mrl::publish_count(status, bid, epoch, block_total);
+        uint32_t before = 0;
+        if (block_total != 0 || last_block)
+            before = mrl::wave_prefix_or_recount(status, bid, epoch, heal, [&](uint32_t j) { return recount_chunk<kV>(p, s_scratch, j); });
+        // the count is globally visible before any wave of this workgroup overwrites a record (a healing
+        // workgroup that does not see the count reads the records as the step's inputs)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&s_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        FSTAMP_SCAN(1);
+        if (last_block && lane == 0) {
+            *reset_count = before + block_total;
+            *next_counter = base + before + block_total;
+        }
+        // Deal the workgroup's finished worlds anew IN their slots of the stepping waves' LDS (record and both agents'
+        // bit vectors), 32 per round, in ascending world order: entry e is the (before + e)-th finished world of the
+        // step (entries of wave w: start_of[w] .. start_of[w + 1]).  Their rows and records are written by the wave
+        // that owns the slot, at the end of its own stream of stores: from here every store would be a round trip of
+        // its own through a saturated fabric (measured: 14 us for five worlds).
+        for (uint32_t e0 = 0; e0 < block_total; e0 += kWorldsPerWave) {
+            const uint32_t here = min((uint32_t)kWorldsPerWave, block_total - e0);
+            uint32_t wv = 0, local = 0;  // entry e0 + (lane & 31): which wave's slot
+            {
+                const uint32_t e = e0 + (lane & 31u);
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; w++) wv += e >= start_of[w] ? 1u : 0u;
+                uint32_t first = 0;
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; w++) first = wv == (uint32_t)w ? start_of[w] : first;
+                local = (lane & 31u) < here ? s_fin[wv][e - first] : 0u;
+            }
+            const WaveLds slot = wave_lds(smem, wv);
+            uint8_t *rec = slot.rec + local * kRecStride;
+            const uint32_t world = bid * kWorldsPerBlock + wv * kWorldsPerWave + local;
+            if (lane < here) {
+                deal_new_game<kR>(p, rec, base + before + e0 + lane);
+                p.active[world] = 1;
+                p.active[(size_t)N + world] = 0;
+            }
+            wave_lds_sync();
+            // the two agents of a fresh game side by side: lanes 0..31 agent 0, lanes 32..63 agent 1
+            if ((lane & 31u) < here) encode_fresh<kV>(p, rec, slot.enc + (local * 2 + (lane >> 5)) * kEncWords, lane >> 5);
+            wave_lds_sync();
+        }
+        if (lane == 0) __hip_atomic_store(&s_ready, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        FSTAMP_SCAN(2);
+        return;
+    }
+
+    // ================= the eight stepping waves =================
+    const WaveLds l = wave_lds(smem, wib);
+    FSTAMP(0);
+    int32_t act0 = 0, act1 = 0;
+    if (lane < nw && !p.sample) {
+        act0 = p.actions[w0 + lane];
+        act1 = p.actions[(size_t)N + w0 + lane];
+    }
+    place_records(l, nw, lane, pending);
+    wave_lds_sync();
+    FSTAMP(1);
+
+    // ---- phase A: act, encode the next mover ----
+    bool over = false, next_is_1 = false;
+    if (lane < nw) {
+        uint8_t *rec = l.rec + lane * kRecStride;
+        const uint32_t world = w0 + lane;
+        const Moved m = move_world<kV>(p, rec, world, act0, act1, true);
+        const uint32_t next = rec[R_CUR] & 1u;
+        next_is_1 = next != 0;
+        encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, next);
+        p.active[(size_t)next * N + world] = 1;
+        p.active[(size_t)(next ^ 1u) * N + world] = 0;
+        p.reward[world] = m.reward;
+        p.reward[(size_t)N + world] = m.reward;
+        over = m.over;
+        p.done[world] = over ? 1 : 0;
+    }
+    const unsigned long long overs = __ballot(over);
+    const unsigned long long movers = __ballot(next_is_1);
+    const uint32_t mine = (uint32_t)__popcll(overs);
+    if (over) s_fin[wib][__popcll(overs & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+    if (lane == 0) s_counts[wib] = mine;
+    FSTAMP(2);
+    mrl::lds_barrier();  // hands the finished worlds to the scan wave
+    FSTAMP(3);
+
+    // ---- phase B: the movers' rows of the worlds that go on ----
+    {
+        const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
+        expand_movers(p, l, nw, overs, movers, out, lane);
+    }
+    FSTAMP(5);
+    // ---- rows of this wave's finished worlds, dealt anew by the scan wave meanwhile; then all 32 records at once ----
+    // (s_ready 1: the workgroup's count is public, records may be overwritten; 2: the fresh games are in LDS too)
+    const uint32_t need = mine != 0 ? 2u : 1u;
+    while (__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+    for (uint32_t j = 0; j < mine; j++) {
+        const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fin[wib][j]);
+        const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)(w0 + who) * kWorldBlock, kWorldBlock);
+#pragma unroll
+        for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {
+            const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
+            row_store(out, f * 16u, agent_chunk(p, l.enc + (who * 2 + agent) * kEncWords, f - agent * kAgentChunks));
+        }
+    }
+    store_records(p, l, w0, nw, lane);
+    FSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1435,7 +1627,7 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
         // steps ahead of a wave that has not passed this step's second barrier)
     }
 
-    for (uint32_t r = 0; r < nw; r++) store_record(p, l, w0, r, lane);
+    store_records(p, l, w0, nw, lane);
     // the counter after the rollout: the last step's counts of everybody (the last workgroup has the
     // highest index, so these are "lower" counts plus its own and the usual wait applies)
     if (last_block && wib == kWavesPerBlock - 1 && num_steps > 0) {
@@ -1471,8 +1663,7 @@ struct HanabiSim final : mrl_sim {
     // single-launch step (mrl_hanabi_step_fused)
     unsigned long long *status = nullptr;
     mrl::AlarmOwner alarm;
-    uint32_t *ticket = nullptr;   // device: tickets handed out so far (episode_scan.hpp)
-    uint32_t tickets_issued = 0;  // host mirror: `grid` per fused launch, mod 2^32
+    mrl::HealTest heal;  // test hook of the healing look-back (mrl_debug_set fused_heal_test)
     uint32_t epoch = 0;
     bool fused = false;
     bool scan_timed_out() const override { return alarm.raised(); }
@@ -1489,12 +1680,11 @@ struct HanabiSim final : mrl_sim {
         const uint32_t *base = counter + parity;
         uint32_t *next = counter + (parity ^ 1u);
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kBlock), 0, stream, a, status, epoch, base, next, reset_count, alarm.alarm(), ticket, tickets_issued); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
         }
         MRL_HIP(hipGetLastError());
-        tickets_issued += grid;
         parity ^= 1u;
     }
 
@@ -1745,12 +1935,14 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         sim->alarm.init(sim->arena);
-        sim->ticket = sim->arena.alloc<uint32_t>(1);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
         {
-            // mrl_debug_set fused_step: 0 = by batch size, 1 = always one launch, 2 = always two
+            // mrl_debug_set fused_step: 0 = the library's choice (one launch whenever a workgroup owns one sub-block),
+            // 1 = one launch where possible, 2 = always two
             const int64_t knob = mrl::debug_get("fused_step", 0);
-            sim->fused = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
+            sim->fused = knob != 2 && sim->params.chunk == (uint32_t)kWorldsPerBlock;
+            sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
+            sim->heal.seen = sim->arena.alloc<uint32_t>(sim->grid);
         }
         {
             // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each

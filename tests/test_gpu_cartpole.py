@@ -110,15 +110,18 @@ def test_planted_terminations_take_episodes_in_world_order(n, pattern, hip_lib, 
     sim.close()
 
 
-@pytest.mark.parametrize("n,steps", [(5000, 120), (300001, 60), (1 << 20, 25)])
-def test_two_phase_equals_single_call(n, steps, hip_lib):
-    """mrl_debug_set("fused_step"): mrl_step as ONE launch (workgroups take a ticket and wait for the lower
-    tickets' counts inside the kernel); the two-phase calls are two launches with the prefix between them.
-    Same numbers either way."""
+@pytest.mark.parametrize("n,steps,heal", [(5000, 120, 0), (300001, 60, 0), (1 << 20, 25, 0), (300001, 40, 3), (70000, 60, 1)],
+                         ids=["5000", "300001", "1M", "300001_late_workgroups", "70000_all_late"])
+def test_two_phase_equals_single_call(n, steps, heal, hip_lib):
+    """mrl_step as ONE launch (every workgroup publishes its finished count, one wave looks back at the lower ones, a count
+    that does not appear is recounted from that workgroup's inputs: csrc/episode_scan.hpp); the two-phase calls are two
+    launches with the prefix between them.  Same numbers either way -- also when workgroups arrive late
+    (`fused_heal_test` = m: workgroups whose index is a multiple of m do nothing until a higher one has recounted
+    them, so the recount path runs against inputs nobody has touched yet)."""
     from madrona_rl_envs_playground_amd._lib import debug_knobs
-    with debug_knobs({"fused_step": 1}):
+    with debug_knobs({"fused_step": 1, "fused_heal_test": heal}):
         s1 = make(n)
-    with debug_knobs({"fused_step": 2}):  # (0 = the library's choice by batch size: one launch up to 1024 worlds)
+    with debug_knobs({"fused_step": 2}):
         s2 = make(n)
     assert s1.kernel_name == "mrl_cartpole_step_fused" and s2.kernel_name == "mrl_cartpole_step"
     torch.manual_seed(1)

@@ -139,13 +139,18 @@ def test_full_game_encoder_matches_generic_encoder(hip_lib):
     slow.close()
 
 
-@pytest.mark.parametrize("cfg,n,steps", [(FULL, 5000, 80), (FULL, 70001, 40), (SMALL, 3000, 60)], ids=["full", "full_70001", "small"])
-def test_single_launch_step_equals_two_phase(cfg, n, steps, hip_lib):
-    """mrl_debug_set("fused_step"): mrl_step as ONE launch (workgroups take a ticket and exchange their finished
-    counts inside the kernel); the two-phase calls are two launches.  Same tensors either way."""
-    with debug_knobs({"fused_step": 1}):
+@pytest.mark.parametrize("cfg,n,steps,heal", [(FULL, 5000, 80, 0), (FULL, 70001, 40, 0), (SMALL, 3000, 60, 0), (FULL, 70001, 60, 3),
+                                              (FULL, 9000, 80, 1), (VERY_SMALL, 3000, 60, 2)],
+                         ids=["full", "full_70001", "small", "full_70001_late_workgroups", "full_9000_all_late", "very_small_late"])
+def test_single_launch_step_equals_two_phase(cfg, n, steps, heal, hip_lib):
+    """mrl_step as ONE launch (every workgroup publishes its finished count, its last wave looks back at the lower ones, a
+    count that does not appear is recounted from that workgroup's records and actions: csrc/episode_scan.hpp); the
+    two-phase calls are two launches.  Same tensors either way -- also when workgroups arrive late (`fused_heal_test`
+    = m: workgroups whose index is a multiple of m do nothing until a higher one has recounted them, so the recount
+    path runs against records nobody has touched yet)."""
+    with debug_knobs({"fused_step": 1, "fused_heal_test": heal}):
         s1 = make(cfg, n)
-    with debug_knobs({"fused_step": 2}):  # (0 = the library's choice by batch size: one launch up to 10000 worlds)
+    with debug_knobs({"fused_step": 2}):
         s2 = make(cfg, n)
     assert s1.kernel_name == "mrl_hanabi_step_fused" and s2.kernel_name == "mrl_hanabi_step"
     gen = torch.Generator(device="cuda").manual_seed(11)
