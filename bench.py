@@ -27,9 +27,17 @@ reported (`timing.blocks` says how many), so that one scheduling hiccup is not t
 
 Also on the line: `roofline` (algorithmic HBM bytes of the step kernel / its average launch duration,
 HIP events on the launch stream over >= 300 back-to-back launches; spec and on-box measured peaks),
-`cpu_baseline` (the test-only CPU oracle in oracle/ on this host's cores, bounded sample), and the
+`cpu_baseline` (the test-only CPU oracle in oracle/ on this host's cores, bounded sample), the
 reference harness's own two timed regions, `wrapped_n_step` (scripts/overcooked_example.py:104-106)
-and `isolated_with_copies` (scripts/overcooked_isolated_example.py:56-65).
+and `isolated_with_copies` (scripts/overcooked_isolated_example.py:56-65), and `other_configs`: the other
+BASELINE.json configurations one GPU can run -- Cartpole 1024 worlds (configs[0]) and 1 M worlds, Hanabi
+65536 worlds (configs[2]: scripts/hanabi_example.py:62-80), the four other standard layouts at the 32768-world
+shard of configs[3] -- each with its kernel, average launch duration over >= 300 launches, algorithmic bytes
+per world-step and roofline fraction.
+
+`roofline.traffic` (and `traffic` of the other legs) are HBM bytes per launch from rocprofv3 PMC passes, which
+cannot run inside this process: they come from profiles/step_traffic.json and are quoted only when that file's
+`csrc_sha16` equals the hash of the sources this library was built from (`_lib.source_hash()`), null otherwise.
 """
 import argparse
 import json
@@ -59,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--no-gather-leg", action="store_true", help="N > 1: skip the obs all-gather leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: only the headline, roofline and cpu_baseline")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the legs of the other BASELINE configurations")
     ap.add_argument("--fused-steps", type=int, default=1000, help="steps of the extra device-side random rollout (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--pool", type=int, default=64, help="pre-sampled action tensors cycled through")
@@ -117,6 +126,96 @@ def cpu_baseline(params, seconds):
     orc.close()
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps x {n} worlds of the same workload ({dt:.1f} s, OpenMP over worlds)"}
+
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` on `workload` from the committed PMC passes -- only if they were taken on THIS build
+    of the kernels (tools/pmc_traffic.py writes the file together with the hash of csrc/)."""
+    from madrona_rl_envs_playground_amd import _lib
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "step_traffic.json")))
+        if pmc["csrc_sha16"] != _lib.source_hash():
+            return None
+        for row in pmc["launches"]:
+            if row["kernel"] == kernel and row["workload"] == workload:
+                return row["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def other_configs(args, torch, local_rank, launches_us):
+    """The other BASELINE.json configurations that fit one GPU, each as one launch (or the library's launches) per step
+    with actions resident in HBM, timed like the headline's roofline: HIP events around back-to-back launches."""
+    from madrona_rl_envs_playground_amd import _lib, layouts
+    from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, ExecMode, HanabiSimulator, OvercookedSimulator
+    launches = max(MIN_ROOFLINE_LAUNCHES, 300)
+    out = {}
+
+    def leg(sim, n, us, workload, note=None, steps_per_launch=1):
+        gbps = sim.bytes_per_world_step * n / (us * 1e-6) / 1e9
+        d = {"workload": workload, "worlds": n, "kernel": sim.kernel_name, "kernel_us_avg": us, "launches_timed": launches,
+             "value": n / (us * 1e-6), "unit": "env-steps/s", "bytes_per_world_step": sim.bytes_per_world_step,
+             "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "traffic": measured_traffic(sim.kernel_name, workload)}
+        if note:
+            d["note"] = note
+        return d
+
+    # configs[3]: the other four standard layouts at the per-GPU shard
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4321)
+    for layout in ("asymmetric_advantages", "coordination_ring", "forced_coordination", "counter_circuit"):
+        params = layouts.get_base_layout_params(layout, args.horizon)
+        n, P = args.worlds, params["num_players"]
+        sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, **params)
+        pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(8)]
+        for i in range(20):
+            sim.step_with_actions(pool[i % 8])
+        us = launches_us(lambda i: sim.step_with_actions(pool[i % 8]), launches)
+        out[f"overcooked_{layout}_{n}"] = leg(sim, n, us, f"overcooked {layout} {n}")
+        sim.close()
+        del pool
+
+    # configs[0] (Cartpole 1024 worlds; the reference runs it on its CPU executor) and the same game at 1 M worlds
+    for n in (1024, 1 << 20):
+        sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n)
+        pool = [torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(8)]
+        for i in range(20):
+            sim.step_with_actions(pool[i % 8])
+        us = launches_us(lambda i: sim.step_with_actions(pool[i % 8]), launches)
+        out[f"cartpole_{n}"] = leg(sim, n, us, f"cartpole {n}",
+                                   note="kernel_us_avg = time per step call back to back; at 1024 worlds that is the host's call rate, not the kernel" if n == 1024 else None)
+        sim.close()
+        del pool
+
+    # configs[2]: Hanabi full game, 65536 worlds.  The reference harness draws argmax(rand * mask) with torch ops between
+    # the steps (scripts/hanabi_example.py:64-67): `harness_loop_us_per_step` is that loop; `kernel_us_avg` is the step
+    # alone, one call per step, with the same uniformly-random-legal-move policy drawn by the step kernel itself
+    # (mrl_rollout_random, one step per call; hanabi.no_persistent keeps it one ordinary launch per step).
+    n = 65536
+    with _lib.debug_knobs({"hanabi.no_persistent": 1}):
+        sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, colors=5, ranks=5, players=2,
+                              max_information_tokens=8, max_life_tokens=3)
+    for i in range(60):
+        sim.rollout_random(1, seed=7, first_step=i)
+    us = launches_us(lambda i: sim.rollout_random(1, seed=7, first_step=60 + i), launches)
+    h = leg(sim, n, us, f"hanabi {n}", note="one step call per launch duration; uniformly random legal moves drawn by the step kernel")
+    mask, act = sim.action_mask_tensor().to_torch(), sim.action_tensor().to_torch()
+
+    def harness(i):
+        act.copy_((torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True))
+        sim.step()
+    for i in range(10):
+        harness(i)
+    h["harness_loop_us_per_step"] = launches_us(harness, 200)
+    sim.close()
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, colors=5, ranks=5, players=2,
+                          max_information_tokens=8, max_life_tokens=3)
+    sim.rollout_random(50, seed=7, first_step=0)
+    h["persistent_rollout_us_per_step"] = launches_us(lambda i: sim.rollout_random(300, seed=7, first_step=50 + 300 * i), 2) / 300
+    sim.close()
+    out[f"hanabi_{n}"] = h
+    return out
 
 
 def run(args):
@@ -359,6 +458,9 @@ def run(args):
         del g_obs
         env.close()
 
+    if single and not args.no_other_configs:
+        extras["other_configs"] = other_configs(args, torch, local_rank, launches_us)
+
     large = None
     if single and args.large_worlds > n:
         # a launch far larger than the 256 MiB Infinity Cache: the kernel, not launch latency or cache residency
@@ -375,15 +477,9 @@ def run(args):
         del big_pool
 
     if rank == 0:
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
-        # inside this process); only reported when they were taken on this exact workload
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "overcooked_step_traffic.json")))
-            if pmc["layout"] == args.layout and pmc["worlds"] == n and pmc["kernel"] == sim.kernel_name:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+        # process): quoted only for this workload, this kernel and this build of csrc/
+        traffic = measured_traffic(sim.kernel_name, f"overcooked {args.layout} {n}")
         bytes_per_launch = sim.bytes_per_world_step * n
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -73,6 +73,19 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources libmrl_envs.so is built from: csrc/*.hip, *.hpp, the Makefile and
+    include/mrl_envs.h.  Measurements that cannot be taken inside a benchmark run (PMC counters: profiles/step_traffic.json)
+    carry it, and are only quoted for the build they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")) or f == "Makefile")
+    for path in [os.path.join(CSRC, f) for f in files] + [HEADER]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

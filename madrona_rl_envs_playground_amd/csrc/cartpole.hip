@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kFusedStepMaxWorlds = 4096;  // mrl_step as one launch up to here, as two above (see create_cartpole)
 
 #define GRAVITY 9.8
 #define MASSCART 1.0
@@ -643,8 +644,13 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         }
         sim->alarm.init(sim->arena);
         {
-            // mrl_debug_set fused_step: 0 = the library's choice (one launch), 1 = one launch, 2 = always two
-            sim->fused_step = mrl::debug_get("fused_step", 0) != 2;
+            // mrl_debug_set fused_step: 0 = the library's choice by batch size, 1 = one launch, 2 = always two.  One launch
+            // wins while the host's call rate is the bound, two once the GPU is: in the single launch every workgroup ends
+            // with look-back + ranking + re-seeding behind its stores, in the pair that tail is a launch of its own that only
+            // touches the finished worlds (tools/fused_crossover.py, us per step one / two launches: 32 worlds 3.8 / 7.6,
+            // 1000 5.9 / 7.4, 10000 7.7 / 7.3, 100000 8.7 / 7.2, 1 M 15.2 / 14.2)
+            const int64_t knob = mrl::debug_get("fused_step", 0);
+            sim->fused_step = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
             sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
             sim->heal.seen = sim->arena.alloc<uint32_t>(sim->fused_grid ? sim->fused_grid : 1);
         }

@@ -177,6 +177,40 @@ def test_bench_starts_its_own_ranks(hip_lib):
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["launches_timed"] >= 300
 
 
+def test_bench_line_carries_every_single_gpu_config(hip_lib):
+    """`python bench.py` (N = 1): besides the headline, `other_configs` holds the other BASELINE.json configurations one
+    GPU can run -- each with kernel, launch duration over >= 300 launches, bytes per world-step and roofline fraction --
+    and every `traffic` is either null or comes from PMC passes taken on exactly this build of csrc/."""
+    from madrona_rl_envs_playground_amd import _lib
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRL_BENCH_REHEARSE", "MRL_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-seconds", "2",
+                           "--large-worlds", "0", "--fused-steps", "100"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["roofline"]["bound"] == "hbm" and out["cpu_baseline"]["kind"] == "port"
+    legs = out["other_configs"]
+    want = [f"overcooked_{name}_32768" for name in STANDARD[1:]] + ["cartpole_1024", "cartpole_1048576", "hanabi_65536"]
+    assert sorted(legs) == sorted(want)
+    for name, leg in legs.items():
+        assert leg["launches_timed"] >= 300 and leg["kernel_us_avg"] > 0 and leg["value"] > 0 and leg["kernel"].startswith("mrl_"), name
+        assert abs(leg["frac"] - leg["bytes_per_world_step"] * leg["worlds"] / (leg["kernel_us_avg"] * 1e-6) / 8e12) < 1e-9
+    assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 2051
+    assert legs["hanabi_65536"]["harness_loop_us_per_step"] > legs["hanabi_65536"]["kernel_us_avg"]
+    # traffic: only ever from this build's PMC passes
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "step_traffic.json")))
+    except OSError:
+        pmc = None
+    same_build = pmc is not None and pmc["csrc_sha16"] == _lib.source_hash()
+    quoted = [out["roofline"]["traffic"]] + [leg["traffic"] for leg in legs.values()]
+    if not same_build:
+        assert all(t is None for t in quoted)
+    else:
+        assert out["roofline"]["traffic"] is not None and 0.9 < out["roofline"]["traffic"] / out["roofline"]["bytes_per_launch"] < 1.3
+
+
 @pytest.mark.parametrize("layout", ["cramped_room", "counter_circuit"])
 def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, oracle_lib):
     """configs[4]: the loop of train/MAPPO/main_player.py:211-261 over the drop-in env.  Both players act
