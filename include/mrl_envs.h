@@ -311,6 +311,17 @@ int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_st
  * sync.  The counter must have been set by mrl_reseed_shard.  No-op for games without an episode counter. */
 int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t num_ranks, uint32_t rank, void *hip_stream);
 
+/* Rollout-buffer side of a trainer.  The reference's MAPPO loop clones the observation
+ * and state tensors after every step and copies them into the buffer slot of that step
+ * (train/MAPPO/main_player.py:245-247, utils/shared_buffer.py:115 chooseinsert).  Here the caller hands the step the
+ * slot instead: from this call on every mrl_step* / mrl_rollout_random / mrl_step_sequence of the simulator writes
+ * its observation slab -- int8 (N, P, H, W, F), the OBS_WORLD_MAJOR layout, `bytes` = N*P*H*W*F -- to obs_dev_or_null
+ * and leaves the OBSERVATION / OBS_WORLD_MAJOR tensors untouched; NULL hands the output back to them.  Same bytes, same
+ * stores, no copy: the kernels take the slab's address from their launch arguments and never read it back.  The
+ * buffer must be 16-byte aligned and stay valid until the work enqueued before the next call of this function has
+ * finished.  Overcooked and Simplecooked (MRL_ERR_INVALID for the other games).  Host-only call: nothing is enqueued. */
+int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t bytes);
+
 /* Sets the simulator's own episode counter (next index handed out). Sharded
  * runs call it once after create with the global world offset semantics the
  * caller wants; it does not touch world state. */

@@ -285,6 +285,22 @@ int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t 
     return guarded([&] { sim->phase2_gathered(counts_dev, num_ranks, rank, (hipStream_t)hip_stream); });
 }
 
+int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t bytes)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    const uint64_t want = sim->observation_bytes();
+    if (want == 0) {
+        mrl::set_error("mrl_set_observation_output: game %d writes no redirectable observation slab (Overcooked and Simplecooked do)", sim->game);
+        return MRL_ERR_INVALID;
+    }
+    if (obs_dev_or_null && (bytes != want || (reinterpret_cast<uintptr_t>(obs_dev_or_null) & 15u))) {
+        mrl::set_error("mrl_set_observation_output: need a 16-byte aligned device buffer of exactly %llu bytes (N x P x H x W x F int8), got %llu at %p",
+                       (unsigned long long)want, (unsigned long long)bytes, obs_dev_or_null);
+        return MRL_ERR_INVALID;
+    }
+    return guarded([&] { sim->set_observation_output(obs_dev_or_null); });
+}
+
 int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;

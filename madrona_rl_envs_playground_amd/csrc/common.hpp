@@ -174,6 +174,10 @@ struct mrl_sim {
     }
     // num_steps, seed, first_step: the uniform random policy on the device (include/mrl_envs.h)
     virtual void rollout_random(uint32_t, uint64_t, uint32_t, hipStream_t) { throw std::runtime_error("this game has no device-side random-policy rollout"); }
+    // mrl_set_observation_output: later steps write their observation slab to `out` (nullptr: the simulator's own buffer
+    // again).  Returns the slab's size in bytes, 0 if the game's observation cannot be redirected.
+    virtual uint64_t set_observation_output(void *) { return 0; }
+    virtual uint64_t observation_bytes() const { return 0; }
     virtual void set_episode_counter(uint32_t, hipStream_t) {}
     virtual void reseed_shard(uint32_t, uint32_t, hipStream_t) {}
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;

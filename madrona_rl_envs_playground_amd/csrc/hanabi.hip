@@ -1063,12 +1063,6 @@ __device__ __forceinline__ void store_records(const HanabiParams &p, const WaveL
     }
 }
 
-__device__ __forceinline__ void store_record(const HanabiParams &p, const WaveLds &l, uint32_t w0, uint32_t r, uint32_t lane)
-{
-    if (lane < kRecordWords)
-        p.records[(size_t)(w0 + r) * kRecordWords + lane] = reinterpret_cast<const uint32_t *>(l.rec + r * kRecStride)[lane];
-}
-
 // Both kernels run on the same grid: workgroup b owns worlds [b*chunk, (b+1)*chunk), p.chunk a
 // multiple of kWorldsPerBlock, and walks it kWorldsPerBlock worlds at a time (episode_scan.hpp).
 // The transition of the workgroup's worlds; returns how many of them finished (to every thread).

@@ -2003,6 +2003,18 @@ struct OvercookedSim final : mrl_sim {
     const char *fixed_name = nullptr;
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
+    uint8_t *own_obs = nullptr;  // the OBS_WORLD_MAJOR buffer; params.obs points elsewhere while the output is redirected
+
+    // The kernels take the slab's address from the launch arguments and never read it back, so writing a step's
+    // observations into a caller's slot (a rollout buffer) instead of the exported tensor is a different pointer in
+    // the same launch: same bytes, same stores.
+    uint64_t observation_bytes() const override { return (uint64_t)num_worlds * params.block_bytes; }
+    uint64_t set_observation_output(void *out) override
+    {
+        params.obs = out ? static_cast<uint8_t *>(out) : own_obs;
+        wide_params.obs = params.obs;
+        return observation_bytes();
+    }
 
     void launch(bool init, const int32_t *actions, hipStream_t stream)
     {
@@ -2106,7 +2118,7 @@ struct OvercookedSim final : mrl_sim {
         case MRL_OVERCOOKED_ACTIVE_AGENT: *out = mrl::make_desc(active, MRL_INT32, device, {P, N}); return true;
         case MRL_OVERCOOKED_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {P, N, 1}); return true;
         case MRL_OVERCOOKED_OBSERVATION:
-            *out = mrl::make_desc(params.obs, MRL_INT8, device, {P * C, N, F}, {F, P * C * F, 1});
+            *out = mrl::make_desc(own_obs, MRL_INT8, device, {P * C, N, F}, {F, P * C * F, 1});
             return true;
         case MRL_OVERCOOKED_ACTION_MASK: *out = mrl::make_desc(mask, MRL_INT32, device, {P, N, 6}); return true;
         case MRL_OVERCOOKED_REWARD: *out = mrl::make_desc(params.reward, MRL_INT32, device, {P, N}); return true;
@@ -2118,7 +2130,7 @@ struct OvercookedSim final : mrl_sim {
             return true;
         case MRL_OVERCOOKED_LOCATION_ID: ensure_ids(); *out = mrl::make_desc(loc_id, MRL_INT32, device, {P * C, N}); return true;
         case MRL_OVERCOOKED_OBS_WORLD_MAJOR:
-            *out = mrl::make_desc(params.obs, MRL_INT8, device, {N, P, (int64_t)H, W, F});
+            *out = mrl::make_desc(own_obs, MRL_INT8, device, {N, P, (int64_t)H, W, F});
             return true;
         case MRL_OVERCOOKED_STATE_PLAYERS: *out = mrl::make_desc(params.players, MRL_UINT8, device, {N, P, 8}); return true;
         case MRL_OVERCOOKED_STATE_OBJECTS: *out = mrl::make_desc(params.cell_obj, MRL_UINT8, device, {N, C, 4}); return true;
@@ -2493,6 +2505,7 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.reward = sim->arena.alloc<int32_t>((size_t)N * P);
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
+        sim->own_obs = a.obs;
         {
             // per row of a group: where its terrain one-hot byte goes in the tile (channel 5P + t - 1, sim.cpp:642-645)
             a.terr_entries = a.wpw * a.rows;

@@ -819,6 +819,13 @@ __global__ void fill_i32(int32_t *dst, int32_t value, size_t count)
 
 struct SimplecookedSim final : mrl_sim {
     SimpleParams params{};
+    uint8_t *own_obs = nullptr;  // the OBS_WORLD_MAJOR buffer; params.obs points elsewhere while the output is redirected
+    uint64_t observation_bytes() const override { return (uint64_t)num_worlds * params.block_bytes; }
+    uint64_t set_observation_output(void *out) override  // see OvercookedSim::set_observation_output
+    {
+        params.obs = out ? static_cast<uint8_t *>(out) : own_obs;
+        return observation_bytes();
+    }
     uint32_t H = 0, grid = 0, lds_bytes = 0;
     using FixedKernel = void (*)(uint32_t *, uint2 *, int2 *, const void *, const uint32_t *, const uint16_t *, uint32_t, uint32_t, const SimpleParams);
     FixedKernel fixed_kernel[3] = {};  // mrl_simplecooked_step_fixed<...> per action source, when the parameters are exactly its
@@ -924,7 +931,7 @@ struct SimplecookedSim final : mrl_sim {
         case MRL_OVERCOOKED_ACTIVE_AGENT: *out = mrl::make_desc(active, MRL_INT32, device, {P, N}); return true;
         case MRL_OVERCOOKED_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {P, N, 1}); return true;
         case MRL_OVERCOOKED_OBSERVATION:
-            *out = mrl::make_desc(params.obs, MRL_INT8, device, {P * C, N, F}, {F, P * C * F, 1});
+            *out = mrl::make_desc(own_obs, MRL_INT8, device, {P * C, N, F}, {F, P * C * F, 1});
             return true;
         case MRL_OVERCOOKED_ACTION_MASK: *out = mrl::make_desc(mask, MRL_INT32, device, {P, N, 6}); return true;
         case MRL_OVERCOOKED_REWARD: *out = mrl::make_desc(params.reward, MRL_INT32, device, {P, N}); return true;
@@ -936,7 +943,7 @@ struct SimplecookedSim final : mrl_sim {
             return true;
         case MRL_OVERCOOKED_LOCATION_ID: ensure_ids(); *out = mrl::make_desc(loc_id, MRL_INT32, device, {P * C, N}); return true;
         case MRL_OVERCOOKED_OBS_WORLD_MAJOR:
-            *out = mrl::make_desc(params.obs, MRL_INT8, device, {N, P, (int64_t)H, W, F});
+            *out = mrl::make_desc(own_obs, MRL_INT8, device, {N, P, (int64_t)H, W, F});
             return true;
         case MRL_OVERCOOKED_STATE_PLAYERS: *out = mrl::make_desc(params.players, MRL_UINT8, device, {N, P, 8}); return true;
         case MRL_OVERCOOKED_STATE_OBJECTS: *out = mrl::make_desc(params.cell_obj, MRL_UINT8, device, {N, C, 4}); return true;
@@ -1174,6 +1181,7 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.reward = sim->arena.alloc<int32_t>((size_t)N * P);
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
+        sim->own_obs = a.obs;
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
         sim->mask = sim->arena.alloc<int32_t>((size_t)N * P * 6, false);

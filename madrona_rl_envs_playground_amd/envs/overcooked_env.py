@@ -65,6 +65,7 @@ class OvercookedMadrona(VectorMultiAgentEnv):
         self._resident = env_device == self.static_dones.device
         self._obs_parts = [(self.static_active_agents[i], self._player_views[i]) for i in range(self.num_players)]
         self._n_actions = self.static_actions.numel()
+        self._redirected_to = 0  # data pointer the simulator's observation output is redirected to (n_step(out=...)), 0 = its own tensor
         self.n_reset()
 
     def _setup_observation_space(self):
@@ -78,19 +79,39 @@ class OvercookedMadrona(VectorMultiAgentEnv):
             return [VectorObservation(active, view) for active, view in self._obs_parts]
         return [VectorObservation(self.to_torch(active), self.to_torch(view)) for active, view in self._obs_parts]
 
-    def n_step(self, actions):
+    def n_step(self, actions, out=None):
+        """``out`` (extension, no reference counterpart): an int8 CUDA tensor of shape (N, P, H, W, F) -- one slot of a
+        rollout buffer.  The step kernel then writes this step's observations THERE instead of the simulator's own tensor
+        and the returned observations are views of ``out``: the per-step clone + insert of the reference's trainer
+        (train/MAPPO/main_player.py:245-247, utils/shared_buffer.py:115) disappears, same bytes written.  ``static_observations``
+        is not refreshed by such a step."""
+        if out is not None:
+            if out.shape != self.static_world_major_observations.shape:
+                raise ValueError(f"out must have the world-major shape {tuple(self.static_world_major_observations.shape)}, got {tuple(out.shape)}")
+            if out.data_ptr() != self._redirected_to:
+                self.sim.set_observation_output(out)
+                self._redirected_to = out.data_ptr()
+        elif self._redirected_to:
+            self.sim.set_observation_output(None)
+            self._redirected_to = 0
         # (P, N, 1) int64/int32 on any device -> the simulator's int32 action tensor
         if (actions.dtype == torch.int64 and actions.device == self.static_actions.device and actions.is_contiguous() and
-                actions.numel() == self._n_actions):
+                actions.shape == self.static_actions.shape):
             # what the reference's harness passes (randint_like of a long tensor): the step kernel reads it as it is and
             # mirrors it into static_actions, which the reference fills with a copy kernel of its own (overcooked_env.py:107)
             self.sim._step_i64_checked(actions.data_ptr())
         else:
             self.static_actions.copy_(actions.to(self.static_actions.device), non_blocking=True)
             self.sim.step()
+        if out is not None:
+            obs = [VectorObservation(self.static_active_agents[i], out[:, i].transpose(1, 2)) for i in range(self.num_players)]
+            if not self._resident:
+                obs = [VectorObservation(self.to_torch(o.active), self.to_torch(o.obs)) for o in obs]
+        else:
+            obs = self.get_obs()
         if self._resident:
-            return self.get_obs(), self.static_rewards, self.static_dones, self.infos
-        return self.get_obs(), self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
+            return obs, self.static_rewards, self.static_dones, self.infos
+        return obs, self.to_torch(self.static_rewards), self.to_torch(self.static_dones), self.infos
 
     def n_reset(self):
         """Like the reference (overcooked_env.py:115-116) this does not restart

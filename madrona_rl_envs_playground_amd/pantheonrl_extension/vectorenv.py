@@ -163,10 +163,11 @@ class VectorMultiAgentEnv(ABC):
         for seat in range(self.n_players - 1):
             self._roster.current(seat).update(rews[self._roster.player_of(seat)], done)
 
-    def step(self, action: torch.Tensor):
-        """One timestep from the ego player's point of view -> (obs, reward, done, info)."""
+    def step(self, action: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """One timestep from the ego player's point of view -> (obs, reward, done, info).  ``out`` (extension): handed
+        to ``n_step`` of environments that can write a step's observations into a caller's buffer slot."""
         joint = self._get_actions(self._obs, action)
-        self._obs, rews, done, info = self.n_step(joint)
+        self._obs, rews, done, info = self.n_step(joint) if out is None else self.n_step(joint, out=out)
         self._update_players(rews, done)
         return self._obs[self.ego_ind], rews[self.ego_ind], done, info
 

@@ -245,6 +245,19 @@ class _Simulator:
         ptr = self._word_pointer(counts, counts.numel(), "counts")
         _lib.check(self._L.mrl_step_phase2_gathered(self._handle, ptr, int(counts.numel()), int(rank), _stream_ptr(self.gpu_id)))
 
+    def set_observation_output(self, out):
+        """Later steps write their observations into ``out`` -- an int8 CUDA tensor of the world-major shape
+        (N, P, H, W, F), contiguous, e.g. one slot of a rollout buffer -- instead of the simulator's own tensor; ``None``
+        hands the output back (``mrl_set_observation_output``; Overcooked and Simplecooked).  The caller keeps ``out``
+        alive while steps that write to it are in flight."""
+        if out is None:
+            _lib.check(self._L.mrl_set_observation_output(self._handle, None, 0))
+            return
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.device.index != self.gpu_id or
+                out.dtype not in (torch.int8, torch.uint8) or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous int8 tensor on cuda:{self.gpu_id}")
+        _lib.check(self._L.mrl_set_observation_output(self._handle, out.data_ptr(), out.numel()))
+
     @property
     def scan_timed_out(self):
         """True once a bounded in-kernel wait has expired (``mrl_scan_timed_out``); every later step raises."""

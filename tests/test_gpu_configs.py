@@ -196,7 +196,7 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
     for name, leg in legs.items():
         assert leg["launches_timed"] >= 300 and leg["kernel_us_avg"] > 0 and leg["value"] > 0 and leg["kernel"].startswith("mrl_"), name
         assert abs(leg["frac"] - leg["bytes_per_world_step"] * leg["worlds"] / (leg["kernel_us_avg"] * 1e-6) / 8e12) < 1e-9
-    assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 2051
+    assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 1901
     assert legs["hanabi_65536"]["harness_loop_us_per_step"] > legs["hanabi_65536"]["kernel_us_avg"]
     # traffic: only ever from this build's PMC passes
     try:
@@ -211,21 +211,25 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
         assert out["roofline"]["traffic"] is not None and 0.9 < out["roofline"]["traffic"] / out["roofline"]["bytes_per_launch"] < 1.3
 
 
-@pytest.mark.parametrize("layout", ["cramped_room", "counter_circuit"])
-def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, oracle_lib):
+@pytest.mark.parametrize("layout,in_place", [("cramped_room", True), ("counter_circuit", True), ("cramped_room", False)],
+                         ids=["cramped_room_into_slot", "counter_circuit_into_slot", "cramped_room_clone_insert"])
+def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, in_place, hip_lib, oracle_lib):
     """configs[4]: the loop of train/MAPPO/main_player.py:211-261 over the drop-in env.  Both players act
     through CNN policies on the int8 observations; replaying the actions they chose through the oracle
-    must reproduce exactly the observations each policy was shown, the rewards and the dones."""
+    must reproduce exactly the observations each policy was shown, the rewards and the dones -- with the
+    step kernel writing every step's observations straight into the rollout buffer's slot (in_place, section 8f item 3:
+    no clone, no insert) and with the reference's clone + insert."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import mappo_rollout_loop as loop
     n, horizon, steps = 512, 30, 75
-    env, ego, buffers = loop.build(layout, n, horizon=horizon, steps_in_buffer=16, seed=5)
+    env, ego, buffers = loop.build(layout, n, horizon=horizon, steps_in_buffer=16, seed=5, in_place=in_place)
     partner = env.partners[0][0]
     ego.keep_inputs = partner.keep_inputs = True
     params = layouts.get_base_layout_params(layout, horizon)
     P, H, W = 2, params["height"], params["width"]
     F = 5 * P + 16
     orc = oracle_lib.OvercookedOracle(params, n, num_threads=4)
+    own = env.static_world_major_observations.clone()  # the simulator's own tensor: untouched while steps go into the slots
 
     def as_env_view(o):  # oracle rows (n, P, C, F) -> per player (n, W, H, F), the wrapper's view
         return o.reshape(n, P, H, W, F).transpose(0, 1, 3, 2, 4)
@@ -240,7 +244,13 @@ def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, ora
         orc.step(acts)
         assert np.array_equal(rew.cpu().numpy(), orc.reward[0]) and np.array_equal(done.cpu().numpy(), orc.done)
         assert np.array_equal(ob_out.obs.cpu().numpy().astype(np.uint8), as_env_view(orc.obs)[:, 0])
-        assert torch.equal(buffers["obs"][t % 16], ob_out.obs)
+        slot = buffers["obs"][t % 16]
+        if in_place:  # the slot IS what the kernel wrote: (n, P, H, W, F), the observation handed out is a view of it
+            assert ob_out.obs.data_ptr() == slot[:, 0].data_ptr()
+            assert np.array_equal(slot.cpu().numpy().astype(np.uint8).reshape(orc.obs.shape), orc.obs)
+            assert torch.equal(env.static_world_major_observations, own)
+        else:
+            assert torch.equal(slot, ob_out.obs)
         seen["steps"] += 1
         seen["dones"] += int(done.sum())
 
@@ -248,6 +258,28 @@ def test_mappo_rollout_loop_policy_sees_oracle_observations(layout, hip_lib, ora
     loop.rollout(env, ego, buffers, ob, steps, on_step=check)
     assert seen["steps"] == steps and seen["dones"] == 2 * n  # two horizons crossed
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["gloo_two_ranks_one_gpu", "nccl_one_rank"])
+def test_mappo_rollout_loop_starts_its_own_ranks(mode, hip_lib):
+    """configs[4] names 8 GPUs: `tools/mappo_rollout_loop.py --gpus N` starts one rank per GPU (env shard + policy
+    replica, no collective in the loop) and rank 0 prints per-rank and summed env-steps/s.  Rehearsed on this one GPU
+    with two gloo ranks, and over nccl (= RCCL) at world_size 1."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRL_BENCH_REHEARSE", "MRL_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    gpus = 2 if mode.startswith("gloo") else 1
+    env["MRL_BENCH_REHEARSE" if gpus == 2 else "MRL_BENCH_FORCE_DIST"] = "1"
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "tools", "mappo_rollout_loop.py"), "--gpus", str(gpus), "--worlds", "4096",
+                           "--steps", "30"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["steps"] == 30 and len(out["per_rank_loop_env_steps_per_s"]) == gpus
+    assert out["ranks"] == {"world_size": gpus, "backend": "gloo" if gpus == 2 else "nccl", "rehearsal_on_one_gpu": gpus == 2}
+    assert 0 < out["loop_env_steps_per_s"] <= out["sum_of_ranks_env_steps_per_s"] * 1.0001
+    assert out["observations"].startswith("written into the buffer slot")
 
 
 def test_several_layouts_as_one_batch(hip_lib):

@@ -544,3 +544,58 @@ def test_random_layouts_against_oracle(seed, hip_lib, oracle_lib):
     assert np.array_equal(sim.state_objects_tensor().to_torch().cpu().numpy(), ob)
     assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts)
     sim.close()
+
+
+@pytest.mark.parametrize("layout,n", [("cramped_room", 4099), ("coordination_ring", 1004), ("counter_circuit", 33000)])  # slots must start on 16-byte boundaries: N x block bytes a multiple of 16
+def test_steps_into_a_ring_of_caller_slots_equal_steps_plus_clones(layout, n, hip_lib, oracle_lib):
+    """mrl_set_observation_output (the rollout-buffer side): K steps whose observations the
+    kernel writes into slot k % T of a caller's ring equal K ordinary steps each followed by a clone (what the reference's
+    trainer does, train/MAPPO/main_player.py:245-247), and equal the oracle; the simulator's own tensor is untouched
+    meanwhile and takes the output back afterwards; the multi-step launches follow the redirect as well."""
+    params = layouts.get_base_layout_params(layout, 25)
+    P = params["num_players"]
+    into, plain = make_sim(params, n), make_sim(params, n)
+    orc = oracle_lib.OvercookedOracle(params, n, num_threads=8)
+    own = into.observation_world_major_tensor().to_torch()
+    before = own.clone()
+    T, K = 5, 23
+    ring = torch.zeros((T,) + tuple(own.shape), dtype=torch.int8, device="cuda")
+    clones = []
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    for k in range(K):
+        a = torch.randint(0, 8, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen).clamp_(max=5)
+        into.set_observation_output(ring[k % T])
+        into.step_with_actions(a)
+        plain.step_with_actions(a)
+        clones.append(plain.observation_world_major_tensor().to_torch().clone())
+        orc.step(a[:, :, 0].cpu().numpy())
+        assert np.array_equal(ring[k % T].cpu().numpy().astype(np.uint8).reshape(orc.obs.shape), orc.obs), f"slot differs from the oracle at step {k}"
+        assert torch.equal(into.reward_tensor().to_torch(), plain.reward_tensor().to_torch())
+        assert torch.equal(into.state_objects_tensor().to_torch(), plain.state_objects_tensor().to_torch())
+    for k in range(K - T, K):
+        assert torch.equal(ring[k % T], clones[k]), f"slot {k % T} != clone of step {k}"
+    assert torch.equal(own, before)  # nothing was written to the simulator's own tensor
+    # multi-step launches follow the redirect: the slot holds the last step's observations
+    into.set_observation_output(ring[0])
+    into.rollout_random(7, seed=5, first_step=0)
+    plain.rollout_random(7, seed=5, first_step=0)
+    assert torch.equal(ring[0], plain.observation_world_major_tensor().to_torch()) and torch.equal(own, before)
+    # ... and NULL hands the output back
+    into.set_observation_output(None)
+    a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+    into.step_with_actions(a)
+    plain.step_with_actions(a)
+    assert torch.equal(own, plain.observation_world_major_tensor().to_torch())
+    # validation: wrong size / dtype / alignment are refused
+    with pytest.raises(Exception):
+        into.set_observation_output(ring[0].flatten()[:-16])
+    with pytest.raises(ValueError):
+        into.set_observation_output(ring[0].to(torch.int32))
+    with pytest.raises(ValueError):
+        into.set_observation_output(ring[0].cpu())
+    if own.numel() % 16 == 0:
+        odd = torch.zeros(own.numel() + 16, dtype=torch.int8, device="cuda")[3:3 + own.numel()]
+        with pytest.raises(Exception, match="aligned"):
+            into.set_observation_output(odd)
+    into.close()
+    plain.close()

@@ -352,3 +352,35 @@ def test_random_kitchens_against_oracle(seed, hip_lib, oracle_lib):
     assert np.array_equal(sim.state_timestep_tensor().to_torch().cpu().numpy(), ts)
     assert np.array_equal(sim.dishes_out_tensor().to_torch().cpu().numpy(), dishes)
     sim.close()
+
+
+def test_env_steps_into_a_callers_slot(hip_lib, oracle_lib):
+    """`env.n_step(actions, out=slot)` (mrl_set_observation_output through the drop-in wrapper): the step kernel writes the
+    observations into the caller's (N, P, H, W, F) slot, the observations handed out are views of it and equal the oracle;
+    without `out` the next step goes back to the simulator's own tensor."""
+    from madrona_rl_envs_playground_amd.envs.overcooked2_env import OvercookedMadrona
+    n = 3002  # slots must start on 16-byte boundaries: N x 1800 bytes a multiple of 16
+    env = OvercookedMadrona("unident_s", n, 0, horizon=30)
+    params = layouts.get_simplecooked_layout_params("unident_s", 30)
+    orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
+    P, H, W = 2, env.height, env.width
+    ring = torch.zeros((3,) + tuple(env.static_world_major_observations.shape), dtype=torch.int8, device="cuda")
+    own = env.static_world_major_observations.clone()
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for t in range(40):
+        a = torch.randint(0, 6, (P, n, 1), device="cuda", generator=gen)  # int64, the harness's dtype
+        slot = ring[t % 3]
+        obs, rew, done, _ = env.n_step(a, out=slot)
+        orc.step(a[:, :, 0].to(torch.int32).cpu().numpy())
+        assert obs[1].obs.data_ptr() == slot[:, 1].data_ptr() and obs[0].obs.shape == (n, W, H, 20) and obs[0].action_mask.all()
+        got = slot.cpu().numpy().astype(np.uint8).reshape(orc.obs.shape)
+        assert np.array_equal(got, orc.obs), f"step {t}"
+        assert np.array_equal(rew.cpu().numpy(), orc.reward) and np.array_equal(done.cpu().numpy(), orc.done)
+        assert torch.equal(env.static_world_major_observations, own)
+    with pytest.raises(ValueError):
+        env.n_step(a, out=ring[0].reshape(-1))
+    obs, _, _, _ = env.n_step(a)  # back to the simulator's own tensor
+    orc.step(a[:, :, 0].to(torch.int32).cpu().numpy())
+    assert obs[0].obs.data_ptr() == env.static_world_major_observations.data_ptr()
+    assert np.array_equal(env.static_world_major_observations.cpu().numpy().astype(np.uint8).reshape(orc.obs.shape), orc.obs)
+    env.close()
