@@ -260,3 +260,27 @@ def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib):
     assert int(one.scan_timeout_tensor().to_torch().item()) == 0
     one.close()
     many.close()
+
+
+@pytest.mark.parametrize("script,n", [("script_card_moves", 200), ("script_empty_deck", 96)])
+def test_known_answers_by_hand_on_gpu(script, n, hip_lib):
+    """tests/hanabi_by_hand.py -- scripted games worked out from the reference text, NOT from the oracle: a successful and a
+    failed play, a discard, the knowledge reset of a redrawn slot, the shift-left of a hand on an empty deck -- replayed
+    through the HIP step: every entry of the mover's observation, the state's own-hand tail and the legal moves, for the
+    single-launch step and for the two-launch pair."""
+    import hanabi_by_hand as by_hand
+    scripts = [getattr(by_hand, script)(w) for w in range(n)]
+    for knob in (1, 2):
+        with debug_knobs({"fused_step": knob}):
+            sim = make(FULL, n)
+
+        def step(acts):
+            sim.step_with_actions(torch.from_numpy(acts).cuda().view(2, n, 1).contiguous())
+
+        def read():
+            return (sim.observation_tensor().to_torch().cpu().numpy(), sim.agent_state_tensor().to_torch().cpu().numpy(),
+                    sim.action_mask_tensor().to_torch().cpu().numpy(), sim.active_agent_tensor().to_torch().cpu().numpy(),
+                    sim.done_tensor().to_torch().cpu().numpy())
+        kinds = by_hand.run_scripts(step, read, scripts)
+        assert len(kinds) >= 3
+        sim.close()

@@ -249,3 +249,40 @@ def test_hint_known_answers_by_hand(oracle_lib):
             assert not other[j, 30:35].any()
     # information tokens: two hints spent (thermometer at 192..199 in the mover's observation)
     assert (orc.obs[0][:, 192:200].sum(-1) == 6).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# Scripted games worked out from the reference text (tests/hanabi_by_hand.py: a second reading of sim.cpp,
+# not the oracle's code): every entry of the mover's observation, state tail and legal moves after a
+# successful play, a failed play, a discard, the knowledge reset of a redrawn slot, and the shift-left
+# of a hand once the deck is empty.  World w of a fresh simulator plays episode w.
+# ---------------------------------------------------------------------------------------------
+def _oracle_io(orc):
+    return (lambda acts: orc.step(acts)), (lambda: (orc.obs, orc.state, orc.mask, orc.active, orc.done))
+
+
+def test_card_moves_known_answers_by_hand(oracle_lib):
+    """Play (successful and failed), discard and the redraw, bit by bit: last-action section incl. card index, card
+    one-hot, scored bit (sim.cpp:158-289); knowledge of a redrawn slot back to "anything" (:584-592)."""
+    import hanabi_by_hand as by_hand
+    n = 64
+    scripts = [by_hand.script_card_moves(w) for w in range(n)]
+    orc = oracle_lib.HanabiOracle(CONFIGS["full"], n)
+    kinds = by_hand.run_scripts(*_oracle_io(orc), scripts)
+    assert (by_hand.PLAY, True) in kinds and (by_hand.PLAY, False) in kinds and (by_hand.DISCARD, False) in kinds
+    assert any(s[-1]["life"] == 1 for s in scripts) and any(s[-1]["life"] == 3 for s in scripts)  # both plays failed / both scored
+
+
+def test_empty_deck_shift_known_answers_by_hand(oracle_lib):
+    """83 scripted moves: the deck runs empty on the 40th redraw, the next play shifts the hand left instead of
+    redrawing (sim.cpp:573-582): four cards, short-hand flag, the fifth knowledge row empty, knowledge moved with the cards,
+    the legal-move scan still reading the stale fifth slot (:416-417)."""
+    import hanabi_by_hand as by_hand
+    n = 24
+    scripts = [by_hand.script_empty_deck(w) for w in range(n)]
+    orc = oracle_lib.HanabiOracle(CONFIGS["full"], n)
+    by_hand.run_scripts(*_oracle_io(orc), scripts)
+    last = [s[-1] for s in scripts]
+    assert all(s["deck"] == 0 and s["obs"][126] == 1 and s["obs"][125] == 0 for s in last)   # the partner's hand is short, mine is not
+    assert all(not s["obs"][100:125].any() and s["legal"][9] == 1 for s in last)           # fifth slot empty; my own five plays stay legal
+    assert any(s["scored"] for s in last) and any(not s["scored"] for s in last)
