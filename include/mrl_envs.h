@@ -371,13 +371,16 @@ const char *mrl_kernel_name(const mrl_sim *sim);
 uint64_t mrl_bytes_per_world_step(const mrl_sim *sim);
 void mrl_destroy(mrl_sim *sim);
 
-/* Test and measurement knobs, consulted by the NEXT mrl_*_create (the library reads no environment
- * variable).  Keys (the list with their meanings: csrc/capi.hip, kDebugKeys): overcooked.wpw, overcooked.whole_max,
- * overcooked.lds_max, overcooked.no_share, overcooked.no_fixed, overcooked.no_direct, overcooked.groups,
- * overcooked.whole_store, overcooked.store_policy, overcooked.wide_rollout, overcooked.variant, hanabi.variant,
- * hanabi.no_persistent, cartpole.no_persistent, fused_step (0 the library's choice, 1 one launch, 2 two launches),
- * fused_heal_test, inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of them.  Unknown key: MRL_ERR_INVALID.
- * No reference counterpart (the reference has MADRONA_* environment variables for its JIT cache only). */
+/* Test and measurement knobs, consulted by every LATER mrl_*_create until they are forgotten again (the library reads no
+ * environment variable).  They are process-global: set them, create, forget them -- the Python binding's `debug_knobs`
+ * context manager does exactly that, also when the create throws.  Keys (with their meanings: csrc/capi.hip, kDebugKeys):
+ * overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.share_max_players, overcooked.share_private,
+ * overcooked.no_share, overcooked.lds_pad, overcooked.no_fixed, overcooked.no_direct, overcooked.whole_store,
+ * overcooked.store_policy, overcooked.wide_rollout, overcooked.groups, overcooked.shared_consts, overcooked.variant,
+ * hanabi.variant, hanabi.no_persistent, cartpole.no_persistent, fused_step (0 the library's choice, 1 one launch,
+ * 2 two launches), fused_heal_test, inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of
+ * them.  Unknown key: MRL_ERR_INVALID.  No reference counterpart (the reference has MADRONA_* environment variables for its
+ * JIT cache only). */
 int mrl_debug_set(const char *key, int64_t value);
 
 /* Measurement aid for bench.py's roofline.peak_measured: one float4 stream over caller buffers on

@@ -101,7 +101,7 @@ __device__ __forceinline__ void shift_history(Row &r, int32_t own, int32_t partn
 }
 
 // workgroup b owns worlds [b*chunk, (b+1)*chunk), chunk a multiple of kBlock
-__global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
+__global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t chunk, const int32_t *action,  // (no __restrict__: mrl_rollout_random passes the ACTION tensor as action_out too)
                                                            int32_t *__restrict__ obs, float *__restrict__ reward,
                                                            int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
                                                            unsigned long long *__restrict__ finished_mask,

@@ -255,7 +255,7 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
 // the two-launch pair above stays for the sharded path, whose episode base comes from the other
 // ranks between the phases.  A workgroup stores its worlds' state only after its count is globally
 // visible (the __syncthreads behind the publication waits for it).
-__global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *__restrict__ action,
+__global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
                                                                   int32_t *__restrict__ done, unsigned long long *status,
                                                                   uint32_t epoch, const uint32_t *__restrict__ episode_base,

@@ -522,7 +522,8 @@ __device__ __forceinline__ void observe_whole(const StepParams &p, const uint8_t
     // bytes of whoever stands there, then stream the slab out.  Three LDS round trips per
     // launch in the dependency chain instead of three per 128-row pass.
     uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
-    const uint32_t nbytes = nw * p.block_bytes;
+    // (backstop: whatever world count the caller derived for the group, nothing is stored past the end of the whole slab)
+    const uint32_t nbytes = min(nw, w0 < p.num_worlds ? p.num_worlds - w0 : 0u) * p.block_bytes;
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(gobs) & 15u);
     uint8_t *tile = s_tile + mis;
     if (!prezeroed) {
@@ -761,7 +762,9 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     // stream the slab out: 16-byte body as raw buffer stores over exactly the body (chunks past its end are
     // dropped by the bounds check, so the four-deep batches need no per-lane branches), then the odd tail bytes
     uint8_t *gobs = p.obs + (size_t)(w0 + l0) * p.block_bytes;
-    const uint32_t nbytes = nl * p.block_bytes;
+    // (backstop: whatever world count the caller derived for the group -- the ragged-batch fault of round 2 was a wrong one --
+    // the descriptor below never reaches past the end of the whole slab)
+    const uint32_t nbytes = min(nl, w0 + l0 < p.num_worlds ? p.num_worlds - (w0 + l0) : 0u) * p.block_bytes;
     const uint8_t *from = tile + __umul24(l0, p.block_bytes);
     const uint32_t head = p.unaligned ? min((16u - ((uint32_t)reinterpret_cast<uintptr_t>(gobs) & 15u)) & 15u, nbytes) : 0u;
     if (lane < head) gobs[lane] = from[lane];

@@ -347,7 +347,7 @@ __device__ __forceinline__ void step_body(const SimpleParams &p)
             cell_reg[k] = i < ncells ? g_obj[i] : 0u;
         }
         // unconditional, clamped indices: behind a branch hipcc consumes a load on the spot
-        const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
+        const uint2 pl_reg = p.players[(size_t)min(w0, N - 1u) * P + (active ? lane : 0u)];  // idle waves (w0 >= N: the grid is rounded up) stay in bounds
         uint32_t a_raw;
         if (p.sample)  // uniform over the six actions (include/mrl_envs.h: mrl_rollout_random)
             a_raw = mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, q), 6u);
@@ -651,7 +651,7 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
     int32_t t = 0, dishes_out = 0;
     {
         const uint32_t *g_obj = p.cell_obj + (size_t)w0 * C;
-        const uint2 pl_reg = p.players[(size_t)w0 * P + (active ? lane : 0u)];
+        const uint2 pl_reg = p.players[(size_t)min(w0, N - 1u) * P + (active ? lane : 0u)];  // idle waves (w0 >= N: the grid is rounded up) stay in bounds
         const int2 clock = p.clock[world];
         const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.terr_off), 0, (int)(p.terr_entries * 2u), 0x00020000);
         uint32_t goff[kGroupTerrPerLane];

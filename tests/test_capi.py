@@ -88,3 +88,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "mrl_oracle" not in text, f
+
+
+def test_header_lists_every_debug_key():
+    """include/mrl_envs.h names the keys mrl_debug_set accepts: the list must be the one csrc/capi.hip checks against."""
+    capi = open(os.path.join(REPO, "madrona_rl_envs_playground_amd", "csrc", "capi.hip")).read()
+    table = capi[capi.index("kDebugKeys[] = {"):capi.index("};", capi.index("kDebugKeys[] = {"))]
+    in_code = set(re.findall(r'^\s*"([a-z_.]+)"', table, flags=re.M))
+    header = open(os.path.join(REPO, "include", "mrl_envs.h")).read()
+    doc = header[header.index("Keys (with their meanings"):header.index("key == NULL forgets")]
+    in_header = set(re.findall(r"\b((?:overcooked|hanabi|cartpole)\.[a-z_]+|fused_step|fused_heal_test|inject_scan_timeout|ablate|stamps)\b", doc))
+    assert in_code == in_header and len(in_code) >= 20

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One launch (ticketed in-kernel prefix) or two per step for Cartpole / Hanabi, by batch size: us per step, call per step
+"""One launch (in-kernel look-back, csrc/episode_scan.hpp) or two per step for Cartpole / Hanabi, by batch size: us per step, call per step
 from Python (what a small batch is bound by) -- the numbers behind the library's default (mrl_debug_set fused_step)."""
 import os, sys, time
 import torch
@@ -23,14 +23,14 @@ for game, sizes in (("cartpole", [32, 1000, 10000, 100000, 262144, 524288, 10485
     for n in sizes:
         row = []
         for knob in (1, 2):
-            _lib.debug_set("fused_step", knob)
+            with _lib.debug_knobs({"fused_step": knob}):
+                if game == "cartpole":
+                    sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
+                else:
+                    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                                          max_information_tokens=8, max_life_tokens=3)
             if game == "cartpole":
-                sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
                 sim.action_tensor().to_torch().copy_(torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda"))
-            else:
-                sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
-                                      max_information_tokens=8, max_life_tokens=3)
-            _lib.debug_set(None, 0)
             row.append((sim.kernel_name, per_step(sim, 2000 if n <= 100000 else 500)))
             sim.close()
         print(f"{game} {n:8d} worlds: one launch {row[0][1]:7.2f} us ({row[0][0]}), two launches {row[1][1]:7.2f} us ({row[1][0]})", flush=True)

@@ -26,13 +26,11 @@ P, n = params["num_players"], args.worlds
 pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda") for _ in range(16)]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for ab in [int(x) for x in args.ablate.split(",")]:
+    knobs = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.knob}
     if ab:
-        _lib.debug_set("ablate", ab)
-    for kv in args.knob:
-        k, v = kv.split("=")
-        _lib.debug_set(k, int(v))
-    sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
-    _lib.debug_set(None, 0)
+        knobs["ablate"] = ab
+    with _lib.debug_knobs(knobs):  # cleared again even if the create throws: the knobs are process-global
+        sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
     for i in range(50):
         sim.step_with_actions(pool[i % 16])
     torch.cuda.synchronize()
