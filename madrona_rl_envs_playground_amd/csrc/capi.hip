@@ -31,6 +31,8 @@ static const char *const kDebugKeys[] = {
     "overcooked.shared_consts",  // 1: constants through the workgroup-shared LDS block + barrier even where a private copy would do
     "overcooked.variant",    // 0: the library's choice; 1: force the generic (lane = world) transition
     "hanabi.variant",        // cap on the encoder variant (0 = the generic encoders)
+    "hanabi.pairing",        // phase A of the single-launch step: 4 (default) four leader waves step their own and wave w + 4's worlds with all
+                             // 64 lanes, 1 the pairs are (2k, 2k + 1), 0 every wave steps its own 32 worlds
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
     "fused_step",            // mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel look-back (episode_scan.hpp) or as

@@ -1329,7 +1329,8 @@ constexpr int kFusedBlock = kBlock + kWave;
 // (nine waves = three on one of the four SIMDs: amdgpu_waves_per_eu(3) holds the kernel to 168 VGPRs)
 template <int kV>
 __global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_eu(3)))
-mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t heal_mod, const HanabiParams p0,
+mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t heal_mod, uint32_t pair_stride,
+                      const HanabiParams p0,
                       unsigned long long *status, uint32_t epoch, const uint32_t *episode_base, uint32_t *next_counter,
                       uint32_t *reset_count, uint32_t *heal_seen)
 {
@@ -1339,10 +1340,13 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     __shared__ uint32_t s_counts[kWavesPerBlock];
     __shared__ uint32_t s_ready;  // 1: the workgroup's count is globally visible, records may be overwritten; 2: the fresh games are in LDS as well
     __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
+    __shared__ uint32_t s_overs[kWavesPerBlock], s_movers[kWavesPerBlock];  // per wave of worlds: finished / next mover is agent 1
     // the records are requested with the kernel's first instructions, from the preloaded arguments alone
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t bid = blockIdx.x;
+    // (pair_stride bit 8, experiment: workgroups 2k and 2k + 1 swap their worlds -- does a slow workgroup follow its XCD or its addresses?)
+    const uint32_t bid = ((pair_stride >> 8) & 1u) && !(gridDim.x & 1u) ? blockIdx.x ^ 1u : blockIdx.x;
+    pair_stride &= 0xFFu;
     const bool scan_wave = wib == (uint32_t)kWavesPerBlock;
     const uint32_t w0 = bid * kWorldsPerBlock + wib * kWorldsPerWave;
     const uint32_t nw = (!scan_wave && w0 < hot_num_worlds) ? min((uint32_t)kWorldsPerWave, hot_num_worlds - w0) : 0u;
@@ -1362,7 +1366,8 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     if (scan_wave) {
         // ================= the scan wave =================
         const uint32_t base = *episode_base;  // requested now, needed after the look-back
-        mrl::lds_barrier();                   // phase A of the eight is through: s_counts and s_fin are there
+        if (pair_stride != 0) mrl::lds_barrier();  // (the stepping waves' hand-over of their records to the leaders)
+        mrl::lds_barrier();                         // phase A is through: s_counts and s_fin are there
         FSTAMP_SCAN(0);
         uint32_t start_of[kWavesPerBlock + 1];
         start_of[0] = 0;
@@ -1418,41 +1423,62 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     }
 
     // ================= the eight stepping waves =================
+    // Phase A is one instruction stream whether 32 or 64 of a wave's lanes are worlds, and two waves of a SIMD running it
+    // side by side take turns at the issue port.  So it is run by FOUR waves ("leaders") with all 64 lanes -- a leader's own
+    // 32 worlds on lanes 0..31 and its partner wave's on lanes 32..63 -- while the partners sleep at the barrier: half the
+    // instructions per SIMD, and the workgroup's first row store that much earlier.  pair_stride: 4 = waves (w, w + 4), the
+    // two waves a SIMD gets when a workgroup's waves are dealt round-robin; 1 = waves (2k, 2k + 1); 0 = every wave for itself.
     const WaveLds l = wave_lds(smem, wib);
     FSTAMP(0);
+    const bool paired = pair_stride != 0;
+    const bool leader = !paired || (pair_stride == 4 ? wib < 4 : (wib & 1u) == 0);
+    const uint32_t half = paired ? lane >> 5 : 0u, idx = paired ? lane & 31u : lane;
+    const uint32_t slot = wib + half * pair_stride;             // whose worlds this lane steps in phase A
+    const uint32_t a_w0 = bid * kWorldsPerBlock + slot * kWorldsPerWave;
+    const uint32_t a_nw = (leader && a_w0 < N) ? min((uint32_t)kWorldsPerWave, N - a_w0) : 0u;
     int32_t act0 = 0, act1 = 0;
-    if (lane < nw && !p.sample) {
-        act0 = p.actions[w0 + lane];
-        act1 = p.actions[(size_t)N + w0 + lane];
+    if (idx < a_nw && !p.sample) {
+        act0 = p.actions[a_w0 + idx];
+        act1 = p.actions[(size_t)N + a_w0 + idx];
     }
     place_records(l, nw, lane, pending);
-    wave_lds_sync();
     FSTAMP(1);
+    if (paired) mrl::lds_barrier();  // the partner's records are in LDS too
+    else wave_lds_sync();
 
     // ---- phase A: act, encode the next mover ----
-    bool over = false, next_is_1 = false;
-    if (lane < nw) {
-        uint8_t *rec = l.rec + lane * kRecStride;
-        const uint32_t world = w0 + lane;
-        const Moved m = move_world<kV>(p, rec, world, act0, act1, true);
-        const uint32_t next = rec[R_CUR] & 1u;
-        next_is_1 = next != 0;
-        encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, next);
-        p.active[(size_t)next * N + world] = 1;
-        p.active[(size_t)(next ^ 1u) * N + world] = 0;
-        p.reward[world] = m.reward;
-        p.reward[(size_t)N + world] = m.reward;
-        over = m.over;
-        p.done[world] = over ? 1 : 0;
+    if (leader) {
+        const WaveLds ls = wave_lds(smem, slot);
+        bool over = false, next_is_1 = false;
+        if (idx < a_nw) {
+            uint8_t *rec = ls.rec + idx * kRecStride;
+            const uint32_t world = a_w0 + idx;
+            const Moved m = move_world<kV>(p, rec, world, act0, act1, true);
+            const uint32_t next = rec[R_CUR] & 1u;
+            next_is_1 = next != 0;
+            encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+            p.active[(size_t)next * N + world] = 1;
+            p.active[(size_t)(next ^ 1u) * N + world] = 0;
+            p.reward[world] = m.reward;
+            p.reward[(size_t)N + world] = m.reward;
+            over = m.over;
+            p.done[world] = over ? 1 : 0;
+        }
+        const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
+        // the half's share of the ballots (a wave for itself: the whole ballot is its "low half", idx = lane < 32 worlds)
+        const uint32_t my_overs = (uint32_t)(half ? all_overs >> 32 : all_overs), my_movers = (uint32_t)(half ? all_movers >> 32 : all_movers);
+        if (over) s_fin[slot][__popc(my_overs & ((1u << idx) - 1u))] = (uint8_t)idx;
+        if (idx == 0) {
+            s_counts[slot] = (uint32_t)__popc(my_overs);
+            s_overs[slot] = my_overs;
+            s_movers[slot] = my_movers;
+        }
     }
-    const unsigned long long overs = __ballot(over);
-    const unsigned long long movers = __ballot(next_is_1);
-    const uint32_t mine = (uint32_t)__popcll(overs);
-    if (over) s_fin[wib][__popcll(overs & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-    if (lane == 0) s_counts[wib] = mine;
     FSTAMP(2);
-    mrl::lds_barrier();  // hands the finished worlds to the scan wave
+    mrl::lds_barrier();  // hands the finished worlds to the scan wave (and a partner's ballots back to it)
     FSTAMP(3);
+    const unsigned long long overs = s_overs[wib], movers = s_movers[wib];
+    const uint32_t mine = (uint32_t)__popcll(overs);
 
     // ---- phase B: the movers' rows of the worlds that go on ----
     {
@@ -1658,6 +1684,7 @@ struct HanabiSim final : mrl_sim {
     unsigned long long *status = nullptr;
     mrl::AlarmOwner alarm;
     mrl::HealTest heal;  // test hook of the healing look-back (mrl_debug_set fused_heal_test)
+    uint32_t pair_stride = 4;  // phase A of the single-launch step by four leader waves (see the kernel); mrl_debug_set hanabi.pairing
     uint32_t epoch = 0;
     bool fused = false;
     bool scan_timed_out() const override { return alarm.raised(); }
@@ -1674,9 +1701,9 @@ struct HanabiSim final : mrl_sim {
         const uint32_t *base = counter + parity;
         uint32_t *next = counter + (parity ^ 1u);
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, a, status, epoch, base, next, reset_count, heal.seen); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
         }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -1937,6 +1964,9 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
             sim->fused = knob != 2 && sim->params.chunk == (uint32_t)kWorldsPerBlock;
             sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
             sim->heal.seen = sim->arena.alloc<uint32_t>(sim->grid);
+            const int64_t pairing = mrl::debug_get("hanabi.pairing", 4);  // 4: waves (w, w + 4), 1: (2k, 2k + 1), 0: no leaders
+            sim->pair_stride = (pairing & 0xFF) == 1 ? 1u : (pairing & 0xFF) == 0 ? 0u : 4u;
+            sim->pair_stride |= (uint32_t)(pairing & 0x100);  // experiment: see the kernel
         }
         {
             // mrl_hanabi_rollout keeps every workgroup alive for the whole rollout and they wait for each

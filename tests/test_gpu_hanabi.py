@@ -284,3 +284,31 @@ def test_known_answers_by_hand_on_gpu(script, n, hip_lib):
         kinds = by_hand.run_scripts(step, read, scripts)
         assert len(kinds) >= 3
         sim.close()
+
+
+@pytest.mark.parametrize("n", [70001, 300])
+def test_phase_a_pairings_agree(n, hip_lib):
+    """The single-launch step runs phase A in four "leader" waves on all 64 lanes (their own worlds and a partner wave's);
+    `hanabi.pairing` picks the partner (4: wave w + 4, 1: wave 2k + 1, 0: every wave for itself).  Same tensors whichever."""
+    sims = []
+    for pairing in (4, 1, 0):
+        with debug_knobs({"fused_step": 1, "hanabi.pairing": pairing}):
+            sims.append(make(FULL, n))
+    assert all(s.kernel_name == "mrl_hanabi_step_fused" for s in sims)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    mask = sims[0].action_mask_tensor().to_torch()
+    names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor", "done_tensor",
+             "game_tensor", "reset_count_tensor"]
+    finished = 0
+    for t in range(70):
+        a = (torch.rand(mask.shape, device="cuda", generator=gen) * mask).argmax(-1, keepdim=True).to(torch.int32)
+        for s in sims:
+            s.step_with_actions(a)
+        for name in names:
+            ref = getattr(sims[0], name)().to_torch()
+            for k, s in enumerate(sims[1:]):
+                assert torch.equal(ref, getattr(s, name)().to_torch()), f"{name}: pairing variant {k + 1} differs at step {t}"
+        finished += int(sims[0].reset_count_tensor().to_torch().item())
+    assert finished > 0
+    for s in sims:
+        s.close()

@@ -6,6 +6,8 @@ os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playg
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import _lib
 _lib.debug_set("stamps", 1)
+if len(sys.argv) > 2:
+    _lib.debug_set("hanabi.pairing", int(sys.argv[2]))
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
