@@ -246,20 +246,22 @@ def run(args):
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if rehearse else "nccl"
-        if rehearse:
-            # gloo's C++ side announces its connections on stdout; stdout carries the one JSON line and nothing else
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
+        # gloo's C++ side announces its connections and RCCL prints its version banner on stdout when the first communicator
+        # comes up; stdout carries the one JSON line and nothing else, so both go to stderr
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
                 dist.init_process_group("gloo")
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(keep, 1)
-                os.close(keep)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()  # brings the communicator up now, inside the redirection
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     params = layouts.get_base_layout_params(args.layout, args.horizon)
     P, n = params["num_players"], args.worlds

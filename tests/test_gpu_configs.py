@@ -273,8 +273,8 @@ def test_mappo_rollout_loop_starts_its_own_ranks(mode, hip_lib):
     proc = subprocess.run([sys.executable, os.path.join(REPO, "tools", "mappo_rollout_loop.py"), "--gpus", str(gpus), "--worlds", "4096",
                            "--steps", "30"], env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
-    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, proc.stdout
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), proc.stdout  # the JSON line and nothing else
     out = json.loads(lines[0])
     assert out["n_gpus"] == gpus and out["steps"] == 30 and len(out["per_rank_loop_env_steps_per_s"]) == gpus
     assert out["ranks"] == {"world_size": gpus, "backend": "gloo" if gpus == 2 else "nccl", "rehearsal_on_one_gpu": gpus == 2}

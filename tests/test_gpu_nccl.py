@@ -38,8 +38,8 @@ def test_bench_rank_protocol_over_nccl_at_world_size_one(hip_lib):
     proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5"],
                           env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
-    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, proc.stdout
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), proc.stdout  # stdout is the JSON line and nothing else (RCCL's banner goes to stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 50 and out["scaling"] == "weak"
     assert out["ranks"] == {"world_size": 1, "backend": "nccl", "rehearsal_on_one_gpu": False}

@@ -157,19 +157,20 @@ def run(args):
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "gloo" if rehearse else "nccl"
-        if rehearse:
-            sys.stdout.flush()
-            keep = os.dup(1)  # gloo's C++ side announces its connections on stdout; stdout carries the JSON line only
-            os.dup2(2, 1)
-            try:
+        sys.stdout.flush()
+        keep = os.dup(1)  # gloo announces its connections and RCCL its version on stdout; stdout carries the JSON line only
+        os.dup2(2, 1)
+        try:
+            if rehearse:
                 dist.init_process_group("gloo")
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(keep, 1)
-                os.close(keep)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     def fence():
         if use_dist:
