@@ -109,16 +109,15 @@ class ShardedSimulator:
     def step(self, actions=None):
         """One step of this rank's worlds.  ``actions``: rank-local action tensor
         (or None to use the simulator's ACTION tensor)."""
-        if not self.needs_episode_exchange:
+        if not self.needs_episode_exchange or not dist.is_initialized():
+            # no exchange to make: Overcooked has no episode counter, and without a process group this one shard IS the whole
+            # batch, so the simulator's own counter is the global one and the library's best single-GPU step applies
             if actions is None:
                 self.sim.step()
             else:
                 self.sim.step_with_actions(actions)
             return
         self.sim.step_phase1(actions)
-        if not dist.is_initialized():
-            self.sim.step_phase2(None)  # one shard = the whole batch: the simulator's own counter is the global one
-            return
         _all_gather_into(self._counts, self._mine, self.group)  # one int32 per rank
         self.sim.step_phase2_gathered(self._counts, self.rank)
 

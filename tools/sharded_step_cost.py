@@ -48,8 +48,18 @@ def main():
         row["two_launch_step_us"] = us(lambda i: sim.step())
         sim.close()
         sh = ShardedSimulator(make, n)
-        row["sharded_step_us"] = us(lambda i: sh.step())
+        row["sharded_step_us"] = us(lambda i: sh.step())  # without a process group: the plain step; with one: + the collective
         sh.close()
+        # the two-phase machinery alone, no collective: phase 1 + the one-workgroup count launch + gathered phase 2
+        sim = make(n)
+        sim.reseed_shard(0, n)
+        counts = sim.shard_count_tensor().to_torch()
+
+        def two_phase(i):
+            sim.step_phase1(None)
+            sim.step_phase2_gathered(counts, 0)
+        row["phase1_count_phase2_gathered_us"] = us(two_phase)
+        sim.close()
         out[name] = row
     print(json.dumps(out))
     if with_group:
