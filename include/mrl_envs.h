@@ -322,6 +322,15 @@ int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t 
  * finished.  Overcooked and Simplecooked (MRL_ERR_INVALID for the other games).  Host-only call: nothing is enqueued. */
 int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t bytes);
 
+/* The same for a whole rollout buffer: a ring of num_slots observation slots, slot s at base + s * slot_stride_bytes (a
+ * multiple of 16, >= N*P*H*W*F).  Step number k counted from this call -- whether it is a launch of its own or step k of a
+ * multi-step launch (mrl_rollout_random, mrl_step_sequence: the kernel moves on to the next slot itself) -- writes its
+ * observations to slot k % num_slots.  One mrl_rollout_random(sim, T, ...) then fills a T-slot buffer with T steps of
+ * random-policy experience in one launch.  base == NULL hands the output back to the simulator's own tensor; one slot is
+ * mrl_set_observation_output.  The count lives on the host: a launch captured in a HIP graph keeps the slot(s) it was
+ * captured with.  Overcooked and Simplecooked. */
+int mrl_set_observation_ring(mrl_sim *sim, void *base_dev_or_null, uint64_t slot_stride_bytes, uint32_t num_slots);
+
 /* Sets the simulator's own episode counter (next index handed out). Sharded
  * runs call it once after create with the global world offset semantics the
  * caller wants; it does not touch world state. */

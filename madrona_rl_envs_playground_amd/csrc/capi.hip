@@ -303,6 +303,23 @@ int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t byt
     return guarded([&] { sim->set_observation_output(obs_dev_or_null); });
 }
 
+int mrl_set_observation_ring(mrl_sim *sim, void *base_dev_or_null, uint64_t slot_stride_bytes, uint32_t num_slots)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    const uint64_t want = sim->observation_bytes();
+    if (want == 0) {
+        mrl::set_error("mrl_set_observation_ring: game %d writes no redirectable observation slab (Overcooked and Simplecooked do)", sim->game);
+        return MRL_ERR_INVALID;
+    }
+    if (base_dev_or_null && (num_slots == 0 || slot_stride_bytes < want || (slot_stride_bytes & 15u) || (reinterpret_cast<uintptr_t>(base_dev_or_null) & 15u))) {
+        mrl::set_error("mrl_set_observation_ring: need a 16-byte aligned device buffer, at least one slot and a slot stride that is a multiple "
+                       "of 16 and >= %llu bytes (N x P x H x W x F int8); got stride %llu, %u slot(s) at %p",
+                       (unsigned long long)want, (unsigned long long)slot_stride_bytes, num_slots, base_dev_or_null);
+        return MRL_ERR_INVALID;
+    }
+    return guarded([&] { sim->set_observation_ring(base_dev_or_null, slot_stride_bytes, num_slots); });
+}
+
 int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream)
 {
     if (int rc = mrl::need(sim)) return rc;

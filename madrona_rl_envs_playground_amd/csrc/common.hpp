@@ -178,6 +178,8 @@ struct mrl_sim {
     // again).  Returns the slab's size in bytes, 0 if the game's observation cannot be redirected.
     virtual uint64_t set_observation_output(void *) { return 0; }
     virtual uint64_t observation_bytes() const { return 0; }
+    // mrl_set_observation_ring: step number k after this call writes its slab to base + (k % num_slots) * stride_bytes
+    virtual void set_observation_ring(void *, uint64_t, uint32_t) {}
     virtual void set_episode_counter(uint32_t, hipStream_t) {}
     virtual void reseed_shard(uint32_t, uint32_t, hipStream_t) {}
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;

@@ -130,6 +130,10 @@ struct StepParams {
     int32_t *reward;
     int32_t *done;
     uint8_t *obs;
+    // mrl_set_observation_ring (multi-step launches): step k of the launch writes slot (ring_first + k) % ring_slots,
+    // ring_stride bytes apart from `obs`; ring_slots <= 1: every step writes `obs`
+    uint64_t ring_stride;
+    uint32_t ring_slots, ring_first;
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -1711,7 +1715,13 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
     // not in the step-to-step chain
     int32_t ahead = 0;
     if (action_seq) ahead = action_seq[(size_t)(active ? q : 0u) * N + world];
+    StepParams ps = p;  // the step's view of the parameters: its observation slot when the output is a ring of slots
+    uint32_t slot = p.ring_first;
     for (uint32_t k = 0; k < num_steps; k++) {
+        if (p.ring_slots > 1u) {
+            ps.obs = p.obs + (size_t)slot * p.ring_stride;
+            slot = slot + 1u == p.ring_slots ? 0u : slot + 1u;
+        }
         uint32_t a;
         if (action_seq) {  // step k's actions from the caller's (num_steps, P, N) array
             a = (uint32_t)ahead;
@@ -1754,10 +1764,10 @@ __device__ __forceinline__ void rollout_body(const StepParams &p, uint32_t num_s
         if (p.patch) {
             // the tile lives as long as the rollout: patch what is dynamic now, stream, put the static rows back
             const uint32_t ndyn = p.direct ? 0u : find_dynamic(p, s_obj, s_cur, s_list, 0, nw, lane);
-            observe_patch<kP, true, kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile + patch_mis, P, w0, 0, nw, lane, hold,
+            observe_patch<kP, true, kPlain>(ps, s_terrain, s_obj, s_pl, s_cur, s_flags, s_prev, s_list, ndyn, s_tile + patch_mis, P, w0, 0, nw, lane, hold,
                                              active, wl, q, posori, held);
         } else {
-            observe_whole<kPlain>(p, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
+            observe_whole<kPlain>(ps, s_terrain, s_obj, s_pl, s_cur, s_flags, s_tile, P, w0, nw, lane);
         }
         if (active) {  // after the stream-out, like the state stores of the single step
             p.reward[(size_t)q * N + world] = reward_world;
@@ -2014,15 +2024,43 @@ struct OvercookedSim final : mrl_sim {
     uint64_t observation_bytes() const override { return (uint64_t)num_worlds * params.block_bytes; }
     uint64_t set_observation_output(void *out) override
     {
-        params.obs = out ? static_cast<uint8_t *>(out) : own_obs;
-        wide_params.obs = params.obs;
+        set_observation_ring(out, 0, 1);
         return observation_bytes();
+    }
+    // a ring of slots: the step number `ring_pos` since this call writes slot ring_pos % slots (host-side count: a
+    // launch captured in a HIP graph keeps the slot it was captured with)
+    uint8_t *ring_base = nullptr;
+    uint64_t ring_stride = 0;
+    uint32_t ring_slots = 1;
+    uint64_t ring_pos = 0;
+    void set_observation_ring(void *base, uint64_t stride_bytes, uint32_t slots) override
+    {
+        ring_base = base ? static_cast<uint8_t *>(base) : own_obs;
+        ring_stride = base ? stride_bytes : 0;
+        ring_slots = base && slots > 1 ? slots : 1;
+        ring_pos = 0;
+        for (StepParams *q : {&params, &wide_params}) {
+            q->obs = ring_base;
+            q->ring_stride = ring_stride;
+            q->ring_slots = ring_slots;
+            q->ring_first = 0;
+        }
+    }
+    // the slot(s) of the next `steps` steps: single-step launches get the slot as their `obs`, multi-step ones the first index
+    uint8_t *take_slots(uint32_t steps, uint32_t *first)
+    {
+        const uint32_t at = (uint32_t)(ring_pos % ring_slots);
+        ring_pos += steps;
+        if (first) *first = at;
+        return ring_base + (size_t)at * ring_stride;
     }
 
     void launch(bool init, const int32_t *actions, hipStream_t stream)
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
+        if (!init) a.obs = take_slots(1, nullptr);
+        a.ring_slots = 1;  // a single step writes exactly its `obs`
         a.per_xcd = ((!init && groups_kernel) ? groups_grid : grid) >> 3;
         const void *hot_actions = a.actions64 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
         // two-player layouts (all five standard ones) exchange through DPP instead of LDS
@@ -2059,6 +2097,8 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
+            take_slots(num_steps, &params.ring_first);
+            wide_params.ring_first = params.ring_first;
             if (wide_rollout)
                 hipLaunchKernelGGL(wide_rollout, dim3(wide_grid), dim3(kWavesPerBlock * kWave), wide_lds, stream, wide_params, num_steps,
                                    seed, first_step, action, (const int32_t *)nullptr);
@@ -2083,6 +2123,8 @@ struct OvercookedSim final : mrl_sim {
     {
         if (num_steps == 0) return;
         if (params.whole) {
+            take_slots(num_steps, &params.ring_first);
+            wide_params.ring_first = params.ring_first;
             if (wide_rollout)
                 hipLaunchKernelGGL(wide_rollout, dim3(wide_grid), dim3(kWavesPerBlock * kWave), wide_lds, stream, wide_params, num_steps,
                                    0ull, 0u, action, actions);
@@ -2509,6 +2551,10 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
         sim->own_obs = a.obs;
+        sim->ring_base = a.obs;
+        a.ring_stride = 0;
+        a.ring_slots = 1;
+        a.ring_first = 0;
         {
             // per row of a group: where its terrain one-hot byte goes in the tile (channel 5P + t - 1, sim.cpp:642-645)
             a.terr_entries = a.wpw * a.rows;

@@ -89,6 +89,10 @@ struct SimpleParams {
     int32_t *reward;
     int32_t *done;
     uint8_t *obs;
+    // mrl_set_observation_ring (multi-step launches): step k of the launch writes slot (ring_first + k) % ring_slots,
+    // ring_stride bytes apart from `obs`; ring_slots <= 1: every step writes `obs`
+    uint64_t ring_stride;
+    uint32_t ring_slots, ring_first;
     // device-side random policy (mrl_rollout_random): actions drawn in the kernel when sample != 0
     uint32_t sample, sample_step;
     uint64_t sample_seed;
@@ -680,9 +684,14 @@ __device__ __forceinline__ void rollout_body(const SimpleParams &p, uint32_t num
 
     const uint32_t plane = __umul24(C, F), shift = 5 * P;
     uint8_t *gobs = p.obs + (size_t)w0 * p.block_bytes;
+    uint32_t slot = p.ring_first;  // the output may be a ring of slots: step k writes slot (ring_first + k) % ring_slots
     int32_t ahead = 0;  // mrl_step_sequence: the next step's action is requested before this step's encode
     if (action_seq) ahead = action_seq[(size_t)(active ? q : 0u) * N + world];
     for (uint32_t k = 0; k < num_steps; k++) {
+        if (p.ring_slots > 1u) {
+            gobs = p.obs + (size_t)slot * p.ring_stride + (size_t)w0 * p.block_bytes;
+            slot = slot + 1u == p.ring_slots ? 0u : slot + 1u;
+        }
         uint32_t a;
         if (action_seq) {
             a = (uint32_t)ahead;
@@ -823,8 +832,29 @@ struct SimplecookedSim final : mrl_sim {
     uint64_t observation_bytes() const override { return (uint64_t)num_worlds * params.block_bytes; }
     uint64_t set_observation_output(void *out) override  // see OvercookedSim::set_observation_output
     {
-        params.obs = out ? static_cast<uint8_t *>(out) : own_obs;
+        set_observation_ring(out, 0, 1);
         return observation_bytes();
+    }
+    uint8_t *ring_base = nullptr;
+    uint64_t ring_stride = 0, ring_pos = 0;
+    uint32_t ring_slots = 1;
+    void set_observation_ring(void *base, uint64_t stride_bytes, uint32_t slots) override  // see OvercookedSim::set_observation_ring
+    {
+        ring_base = base ? static_cast<uint8_t *>(base) : own_obs;
+        ring_stride = base ? stride_bytes : 0;
+        ring_slots = base && slots > 1 ? slots : 1;
+        ring_pos = 0;
+        params.obs = ring_base;
+        params.ring_stride = ring_stride;
+        params.ring_slots = ring_slots;
+        params.ring_first = 0;
+    }
+    uint8_t *take_slots(uint32_t steps, uint32_t *first)
+    {
+        const uint32_t at = (uint32_t)(ring_pos % ring_slots);
+        ring_pos += steps;
+        if (first) *first = at;
+        return ring_base + (size_t)at * ring_stride;
     }
     uint32_t H = 0, grid = 0, lds_bytes = 0;
     using FixedKernel = void (*)(uint32_t *, uint2 *, int2 *, const void *, const uint32_t *, const uint16_t *, uint32_t, uint32_t, const SimpleParams);
@@ -836,8 +866,11 @@ struct SimplecookedSim final : mrl_sim {
     int32_t *action = nullptr, *active = nullptr, *mask = nullptr;
     int32_t *world_id = nullptr, *agent_id = nullptr, *loc_world_id = nullptr, *loc_id = nullptr;
 
-    void launch(bool init, const SimpleParams &a, hipStream_t stream)
+    void launch(bool init, const SimpleParams &given, hipStream_t stream)
     {
+        SimpleParams a = given;
+        if (!init) a.obs = take_slots(1, nullptr);
+        a.ring_slots = 1;  // a single step writes exactly its `obs`
         if (init) {
             if (a.P == 2)
                 hipLaunchKernelGGL((mrl_simplecooked_step<true, 2>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);
@@ -877,6 +910,7 @@ struct SimplecookedSim final : mrl_sim {
         if (params.P != 2 || !params.flat) return false;
         SimpleParams a = params;
         a.action_out = action;
+        take_slots(num_steps, &a.ring_first);
         if (fixed_rollout)
             hipLaunchKernelGGL(fixed_rollout, dim3(grid), dim3(kBlock), lds_bytes, stream, a, num_steps, seed, first_step, action_seq);
         else
@@ -1182,6 +1216,10 @@ mrl_sim *mrl::create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, 
         a.done = sim->arena.alloc<int32_t>(N);
         a.obs = sim->arena.alloc<uint8_t>((size_t)N * a.block_bytes, false);
         sim->own_obs = a.obs;
+        sim->ring_base = a.obs;
+        a.ring_stride = 0;
+        a.ring_slots = 1;
+        a.ring_first = 0;
         sim->action = sim->arena.alloc<int32_t>((size_t)N * P);
         sim->active = sim->arena.alloc<int32_t>((size_t)N * P, false);
         sim->mask = sim->arena.alloc<int32_t>((size_t)N * P * 6, false);

@@ -258,6 +258,18 @@ class _Simulator:
             raise ValueError(f"out must be a contiguous int8 tensor on cuda:{self.gpu_id}")
         _lib.check(self._L.mrl_set_observation_output(self._handle, out.data_ptr(), out.numel()))
 
+    def set_observation_ring(self, ring):
+        """``ring``: an int8 CUDA tensor (T, N, P, H, W, F) whose slots ``ring[s]`` are contiguous -- a rollout buffer.  Step
+        number k from this call on writes its observations to ``ring[k % T]``, whether it is a call of its own or step k of
+        ``rollout_random`` / ``step_sequence`` (``mrl_set_observation_ring``); ``None`` hands the output back."""
+        if ring is None:
+            _lib.check(self._L.mrl_set_observation_ring(self._handle, None, 0, 0))
+            return
+        if (not isinstance(ring, torch.Tensor) or not ring.is_cuda or ring.device.index != self.gpu_id or ring.dim() < 2 or
+                ring.dtype not in (torch.int8, torch.uint8) or not ring[0].is_contiguous()):
+            raise ValueError(f"ring must be an int8 tensor (T, N, P, H, W, F) on cuda:{self.gpu_id} with contiguous slots")
+        _lib.check(self._L.mrl_set_observation_ring(self._handle, ring.data_ptr(), int(ring.stride(0)), int(ring.shape[0])))
+
     @property
     def scan_timed_out(self):
         """True once a bounded in-kernel wait has expired (``mrl_scan_timed_out``); every later step raises."""

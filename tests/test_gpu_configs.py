@@ -282,13 +282,14 @@ def test_mappo_rollout_loop_starts_its_own_ranks(mode, hip_lib):
     assert out["observations"].startswith("written into the buffer slot")
 
 
-def test_several_layouts_as_one_batch(hip_lib):
+@pytest.mark.parametrize("graph", [False, True], ids=["forked_streams", "one_captured_graph"])
+def test_several_layouts_as_one_batch(graph, hip_lib):
     """OvercookedMultiLayout: the five standard layouts stepped side by side on their own streams give, layout by
-    layout, what five separate envs give."""
+    layout, what five separate envs give -- issued call by call, and as ONE captured HIP graph replayed per step."""
     from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
     from madrona_rl_envs_playground_amd.envs.multi_layout import OvercookedMultiLayout
     counts = [300, 77, 512, 64, 129]
-    multi = OvercookedMultiLayout(STANDARD, counts, 0, horizon=35)
+    multi = OvercookedMultiLayout(STANDARD, counts, 0, horizon=35, graph=graph)
     singles = [OvercookedMadrona(name, n, 0, horizon=35) for name, n in zip(STANDARD, counts)]
     gen = torch.Generator(device="cuda").manual_seed(21)
     for _ in range(80):

@@ -599,3 +599,62 @@ def test_steps_into_a_ring_of_caller_slots_equal_steps_plus_clones(layout, n, hi
             into.set_observation_output(odd)
     into.close()
     plain.close()
+
+
+@pytest.mark.parametrize("layout,n", [("cramped_room", 4100), ("counter_circuit", 1000), ("multiplayer_schelling", 128), ("coordination_ring", 33000)])
+def test_multi_step_launches_fill_a_ring_of_slots(layout, n, hip_lib):
+    """mrl_set_observation_ring: step k from the call on writes its observations to slot k % T of the caller's buffer -- inside
+    ONE multi-step launch (mrl_rollout_random, mrl_step_sequence: the kernel moves from slot to slot itself), across launches,
+    and for single steps.  Every slot must hold exactly what a twin simulator, stepped one launch at a time, shows after that step."""
+    params = layouts.get_base_layout_params(layout, 30)
+    P = params["num_players"]
+    ringed, twin = make_sim(params, n), make_sim(params, n)
+    own = ringed.observation_world_major_tensor().to_torch()
+    before = own.clone()
+    T = 6
+    slot_bytes = (own.numel() + 15) // 16 * 16  # slots start on 16-byte boundaries whatever N
+    store = torch.zeros(T * slot_bytes, dtype=torch.int8, device="cuda")
+    ring = torch.as_strided(store, (T,) + tuple(own.shape), (slot_bytes,) + tuple(own.stride()))
+    ringed.set_observation_ring(ring)
+    history = []  # observations after every step, from the twin
+
+    def twin_random(steps, seed, first):
+        for k in range(steps):
+            twin.rollout_random(1, seed=seed, first_step=first + k)
+            history.append(twin.observation_world_major_tensor().to_torch().clone())
+
+    def check(tag):
+        k_total = len(history)
+        for k in range(max(0, k_total - T), k_total):
+            assert torch.equal(ring[k % T], history[k]), f"{tag}: slot {k % T} is not the observation after step {k}"
+        assert torch.equal(own, before), f"{tag}: the simulator's own tensor was written"
+
+    ringed.rollout_random(4, seed=11, first_step=0)          # slots 0..3
+    twin_random(4, 11, 0)
+    check("first launch")
+    ringed.rollout_random(9, seed=11, first_step=4)          # wraps around the ring one and a half times
+    twin_random(9, 11, 4)
+    check("wrapping launch")
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    seq = torch.randint(0, 6, (5, P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+    ringed.step_sequence(seq)                                # an open-loop action sequence, one launch
+    for k in range(5):
+        twin.step_with_actions(seq[k])
+        history.append(twin.observation_world_major_tensor().to_torch().clone())
+    check("action sequence")
+    for k in range(4):                                       # single steps take their slots from the same count
+        a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+        ringed.step_with_actions(a)
+        twin.step_with_actions(a)
+        history.append(twin.observation_world_major_tensor().to_torch().clone())
+    check("single steps")
+    assert torch.equal(ringed.state_objects_tensor().to_torch(), twin.state_objects_tensor().to_torch())
+    assert torch.equal(ringed.reward_tensor().to_torch(), twin.reward_tensor().to_torch())
+    ringed.set_observation_ring(None)
+    ringed.rollout_random(3, seed=2, first_step=0)
+    twin.rollout_random(3, seed=2, first_step=0)
+    assert torch.equal(own, twin.observation_world_major_tensor().to_torch())
+    with pytest.raises(Exception, match="stride"):
+        ringed.set_observation_ring(torch.zeros((2, own.numel() - 16), dtype=torch.int8, device="cuda"))
+    ringed.close()
+    twin.close()

@@ -384,3 +384,29 @@ def test_env_steps_into_a_callers_slot(hip_lib, oracle_lib):
     assert obs[0].obs.data_ptr() == env.static_world_major_observations.data_ptr()
     assert np.array_equal(env.static_world_major_observations.cpu().numpy().astype(np.uint8).reshape(orc.obs.shape), orc.obs)
     env.close()
+
+
+def test_rollout_fills_a_ring_of_slots(hip_lib):
+    """mrl_set_observation_ring for Simplecooked: one mrl_rollout_random launch of K steps leaves step k's observations in slot
+    k % T; single steps continue the count."""
+    params = layouts.get_simplecooked_layout_params("simple", 40)
+    n, T = 4096, 4
+    ringed, twin = make_sim(params, n), make_sim(params, n)
+    own = ringed.observation_world_major_tensor().to_torch()
+    before = own.clone()
+    ring = torch.zeros((T,) + tuple(own.shape), dtype=torch.int8, device="cuda")
+    ringed.set_observation_ring(ring)
+    ringed.rollout_random(10, seed=3, first_step=0)
+    history = []
+    for k in range(10):
+        twin.rollout_random(1, seed=3, first_step=k)
+        history.append(twin.observation_world_major_tensor().to_torch().clone())
+    a = torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda")
+    ringed.step_with_actions(a)
+    twin.step_with_actions(a)
+    history.append(twin.observation_world_major_tensor().to_torch().clone())
+    for k in range(len(history) - T, len(history)):
+        assert torch.equal(ring[k % T], history[k]), f"slot {k % T} is not the observation after step {k}"
+    assert torch.equal(own, before)
+    ringed.close()
+    twin.close()
