@@ -12,8 +12,10 @@ shift-left of removeFromHand (:567-594), the deal (rng.hpp:7-36, drawDeck :45-52
     game.own_hand(observer)         # the 125 entries encodeOwnHand appends to the state
     game.legal(observer)            # the 20 entries of generateActionMask
 
-Only what the scripts need is modelled: information tokens never exceed their maximum here (the shifted encoding of
-sim.cpp:676-678 is the oracle's business), the game is never over.
+Information tokens may exceed their maximum: completing a firework adds one unconditionally (sim.cpp:676-678), the
+reference then writes a longer thermometer with its running offset (:119-125) and every later section moves up; what no
+longer fits the 658 / 783 entries of a row is cut off here (the reference writes it past the end of its array).  The game
+is never over in a script.
 """
 import numpy as np
 
@@ -104,8 +106,7 @@ class Game:
         if self.fireworks[colour] == rank:
             self.fireworks[colour] += 1
             completed = self.fireworks[colour] == R
-            assert not (completed and self.info == MAX_INFO), "script error: tokens would exceed their maximum"
-            self.info += 1 if completed else 0
+            self.info += 1 if completed else 0  # unconditionally: may exceed MAX_INFO (sim.cpp:676-678)
             self.last.update(scored=True, info_token=completed)
         else:
             self.discards[card] += 1
@@ -156,7 +157,7 @@ class Game:
         v += [int(i < len(self.deck)) for i in range(40)]
         for c in range(K):
             v += [int(i + 1 == self.fireworks[c]) for i in range(R)]
-        v += [int(i < self.info) for i in range(MAX_INFO)]
+        v += [1] * self.info + [0] * max(0, MAX_INFO - self.info)  # two loops with a running offset (:119-125): longer when info > max
         v += [int(i < self.life) for i in range(MAX_LIFE)]
         # encodeDiscards (:137-156)
         for card in range(K * R):
@@ -187,8 +188,12 @@ class Game:
                     v += [int(hand.known_rank[slot] == r) for r in range(R)]
                 else:
                     v += [0] * (K * R + K + R)
-        assert len(v) == 658
+        assert len(v) == 658 + max(0, self.info - MAX_INFO)
         return np.array(v, dtype=np.uint8)
+
+    def state(self, me):
+        """copyObsToState + encodeOwnHand (:333-365): the observation as long as it came out, then the own hand; 783 entries fit."""
+        return np.concatenate([self.observation(me), self.own_hand(me)])[:783]
 
     def own_hand(self, me):
         """encodeOwnHand (:343-365): what the state carries behind the observation."""
@@ -211,8 +216,8 @@ class Game:
 def snapshot(g, uid, actor):
     """What the reference leaves visible after a move: the NEXT mover's fresh observation, state tail and legal moves."""
     me = g.mover
-    return dict(uid=uid, actor=actor, mover=me, obs=g.observation(me), own=g.own_hand(me), legal=g.legal(me), info=g.info, life=g.life,
-                deck=len(g.deck), scored=g.last["scored"], move=g.last["move"])
+    return dict(uid=uid, actor=actor, mover=me, obs=g.observation(me)[:658], own=g.own_hand(me), state=g.state(me), legal=g.legal(me),
+                info=g.info, life=g.life, deck=len(g.deck), scored=g.last["scored"], info_token=g.last["info_token"], move=g.last["move"])
 
 
 def script_card_moves(episode):
@@ -259,27 +264,69 @@ def script_empty_deck(episode):
 
 
 def run_scripts(sim_step, read, scripts):
-    """scripts[w] = snapshots of world w's game (same length for all w).  `sim_step(actions (2, n) int32)` advances the
-    implementation under test, `read()` returns (obs (2, n, 658), state (2, n, 783), mask (2, n, 20), active (2, n), done (n,))."""
-    n, steps = len(scripts), len(scripts[0])
+    """scripts[w] = snapshots of world w's game, or None; lengths may differ.  `sim_step(actions (2, n) int32)` advances the
+    implementation under test, `read()` returns (obs (2, n, 658), state (2, n, 783), mask (2, n, 20), active (2, n), done (n,)).
+    A world whose script is over (or that has none) goes on with the first legal move its own mask offers and is no longer
+    looked at."""
+    n = len(scripts)
+    steps = max(len(sc) for sc in scripts if sc)
     kinds = set()
     for t in range(steps):
         acts = np.zeros((2, n), np.int32)
+        filler = [w for w in range(n) if not scripts[w] or t >= len(scripts[w])]
+        if filler:
+            _, _, mask, active, _ = read()
+            for w in filler:
+                me = int(active[1, w] != 0)
+                acts[me, w] = int(np.flatnonzero(mask[me, w])[0])
         for w in range(n):
-            acts[scripts[w][t]["actor"], w] = scripts[w][t]["uid"]
+            if scripts[w] and t < len(scripts[w]):
+                acts[scripts[w][t]["actor"], w] = scripts[w][t]["uid"]
         sim_step(acts)
         obs, state, mask, active, done = read()
-        assert not done.any(), f"a scripted game ended at move {t}"
         for w in range(n):
+            if not scripts[w] or t >= len(scripts[w]):
+                continue
             snap = scripts[w][t]
             me = snap["mover"]
+            assert not done[w], f"world {w}: the scripted game ended at move {t}"
             assert active[me, w] == 1 and active[1 - me, w] == 0
             got = obs[me, w].astype(np.uint8)
             if not np.array_equal(got, snap["obs"]):
                 bad = np.flatnonzero(got != snap["obs"])
                 raise AssertionError(f"world {w}, move {t} (action {snap['uid']}): observation entries {bad[:12].tolist()} differ from the by-hand answer")
-            assert np.array_equal(state[me, w, :658].astype(np.uint8), snap["obs"]), (w, t)
-            assert np.array_equal(state[me, w, 658:783].astype(np.uint8), snap["own"]), f"world {w}, move {t}: own-hand tail of the state"
+            assert np.array_equal(state[me, w, :783].astype(np.uint8), snap["state"]), f"world {w}, move {t}: state (observation + own hand)"
             assert np.array_equal(mask[me, w], snap["legal"]), f"world {w}, move {t}: legal moves"
-            kinds.add((snap["move"], bool(snap["scored"])))
+            kinds.add((snap["move"], bool(snap["scored"]), bool(snap["info_token"]), snap["info"] > MAX_INFO))
     return kinds
+
+
+def script_complete_a_firework(episode, max_moves=140, after=4):
+    """Both players play whatever is playable (the script knows every card), otherwise discard their first card when a token
+    is missing, otherwise name the colour of the partner's first card -- until a firework is completed WHILE all eight
+    information tokens are there: the ninth token (sim.cpp:676-678) lengthens the thermometer and moves every later section
+    of the observation up by one.  `after` more moves follow under the same rule (a hint brings the count back to eight).
+    Returns the snapshots, or None if this episode's deal does not get there."""
+    g = Game(episode)
+    steps, countdown = [], None
+    for _ in range(max_moves):
+        me = g.hands[g.mover]
+        playable = [s for s in range(me.size) if g.fireworks[me.cards[s] // R] == me.cards[s] % R]
+        if playable:
+            kind, value = "play", max(playable, key=lambda s: me.cards[s] % R)
+        elif g.info < MAX_INFO:
+            kind, value = "discard", 0
+        else:
+            kind, value = "hint_colour", g.hands[1 - g.mover].cards[0] // R
+        uid, actor = g.action_id(kind, value), g.mover
+        getattr(g, kind)(value)
+        if not g.deck or g.life < 1 or sum(g.fireworks) >= K * R:
+            return None  # the endgame is not this script's subject
+        steps.append(snapshot(g, uid, actor))
+        if countdown is None and g.last["info_token"] and g.info > MAX_INFO:
+            countdown = after
+        elif countdown is not None:
+            countdown -= 1
+            if countdown == 0:
+                return steps
+    return None

@@ -262,10 +262,11 @@ def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib):
     many.close()
 
 
-@pytest.mark.parametrize("script,n", [("script_card_moves", 200), ("script_empty_deck", 96)])
+@pytest.mark.parametrize("script,n", [("script_card_moves", 200), ("script_empty_deck", 96), ("script_complete_a_firework", 300)])
 def test_known_answers_by_hand_on_gpu(script, n, hip_lib):
     """tests/hanabi_by_hand.py -- scripted games worked out from the reference text, NOT from the oracle: a successful and a
-    failed play, a discard, the knowledge reset of a redrawn slot, the shift-left of a hand on an empty deck -- replayed
+    failed play, a discard, the knowledge reset of a redrawn slot, the shift-left of a hand on an empty deck, a completed
+    firework with the ninth information token and its shifted encoding -- replayed
     through the HIP step: every entry of the mover's observation, the state's own-hand tail and the legal moves, for the
     single-launch step and for the two-launch pair."""
     import hanabi_by_hand as by_hand

@@ -269,7 +269,7 @@ def test_card_moves_known_answers_by_hand(oracle_lib):
     scripts = [by_hand.script_card_moves(w) for w in range(n)]
     orc = oracle_lib.HanabiOracle(CONFIGS["full"], n)
     kinds = by_hand.run_scripts(*_oracle_io(orc), scripts)
-    assert (by_hand.PLAY, True) in kinds and (by_hand.PLAY, False) in kinds and (by_hand.DISCARD, False) in kinds
+    assert {(by_hand.PLAY, True, False, False), (by_hand.PLAY, False, False, False), (by_hand.DISCARD, False, False, False)} <= kinds
     assert any(s[-1]["life"] == 1 for s in scripts) and any(s[-1]["life"] == 3 for s in scripts)  # both plays failed / both scored
 
 
@@ -286,3 +286,19 @@ def test_empty_deck_shift_known_answers_by_hand(oracle_lib):
     assert all(s["deck"] == 0 and s["obs"][126] == 1 and s["obs"][125] == 0 for s in last)   # the partner's hand is short, mine is not
     assert all(not s["obs"][100:125].any() and s["legal"][9] == 1 for s in last)           # fifth slot empty; my own five plays stay legal
     assert any(s["scored"] for s in last) and any(not s["scored"] for s in last)
+
+
+def test_completed_firework_and_ninth_token_known_answers_by_hand(oracle_lib):
+    """Scripted games in which a firework is completed while all eight information tokens are there: the "information token
+    added" bit of the last action (sim.cpp:676-678, :281-285), fireworks beyond the first rank, and the NINTH token -- the
+    thermometer comes out one entry longer and every later section of the observation and of the state sits one entry
+    higher (what no longer fits the row is cut off) -- until a hint spends it again."""
+    import hanabi_by_hand as by_hand
+    n = 96
+    scripts = [by_hand.script_complete_a_firework(w) for w in range(n)]
+    assert sum(sc is not None for sc in scripts) > 40
+    orc = oracle_lib.HanabiOracle(CONFIGS["full"], n)
+    kinds = by_hand.run_scripts(*_oracle_io(orc), scripts)
+    assert (by_hand.PLAY, True, True, True) in kinds                      # the completing play, seen with nine tokens
+    assert any(k[3] and k[0] != by_hand.PLAY for k in kinds) or any(k[3] and not k[2] for k in kinds)  # a later move seen shifted
+    assert any(k[0] == by_hand.REVEAL_COLOUR and not k[3] for k in kinds)
