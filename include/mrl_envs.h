@@ -267,6 +267,19 @@ int mrl_balance_create(int gpu_id, uint32_t num_worlds, mrl_sim **out);
  * word in mapped host memory: no device call, no sync). */
 int mrl_step(mrl_sim *sim, void *hip_stream);
 
+/* HIP graphs.  Every mrl_step* / mrl_rollout_random / mrl_step_sequence only enqueues kernels on the stream it is given, so
+ * Overcooked and Simplecooked calls can be captured (hipStreamBeginCapture, torch.cuda.graph) and replayed as they are.
+ * Hanabi, Cartpole and the balance beam keep launch-to-launch state on the host by default (which half of the
+ * double-buffered episode counter is current, the epoch of the single-launch step's look-back) and pass it in kernel
+ * arguments; captured as such, a replay would run with stale values, so those calls return MRL_ERR_INVALID while the stream
+ * is capturing.  mrl_prepare_graph_capture(sim, stream) -- called once, OUTSIDE a capture; it synchronises the stream --
+ * moves that state into device memory for the rest of the simulator's life: every step then enqueues a one-thread launch
+ * that advances it in front of its kernels, which read it from there, and captured steps replay correctly (a replay of K
+ * captured steps is K more steps).  The price is that extra launch per step (~2 us of GPU time), also outside graphs, and
+ * mrl_rollout_random runs one launch per step on such a simulator (its persistent form is a cooperative launch, which
+ * cannot be captured).  No-op for Overcooked and Simplecooked. */
+int mrl_prepare_graph_capture(mrl_sim *sim, void *hip_stream);
+
 /* Launch shape of the simulator's step kernel: out = {workgroups, threads per workgroup, LDS bytes per
  * workgroup, worlds per wavefront (0 where that is not how the game is mapped)}.  For DESIGN.md's
  * occupancy arithmetic and the tests that guard it; no reference counterpart. */

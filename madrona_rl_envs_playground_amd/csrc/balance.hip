@@ -166,9 +166,9 @@ constexpr uint32_t kTripWords = 64;  // mask words (64 worlds each) the reset la
 template <bool kAll>
 __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t chunk, const unsigned long long *__restrict__ finished_mask,
                                                             int32_t *__restrict__ obs, const uint32_t *__restrict__ block_counts,
-                                                            const uint32_t *__restrict__ episode_base, uint32_t world_offset,
-                                                            uint32_t *__restrict__ next_counter, uint32_t *__restrict__ reset_count,
-                                                            const mrl::GatheredCounts gathered)
+                                                            const uint32_t *episode_base, uint32_t world_offset,
+                                                            uint32_t *next_counter, uint32_t *__restrict__ reset_count,
+                                                            const mrl::GatheredCounts gathered, const mrl::DeviceCounter device_counter)
 {
     __shared__ uint32_t s_red[2 * kBlock / 64];
     __shared__ unsigned long long s_word[kTripWords];
@@ -188,6 +188,8 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t
     }
     const uint32_t words = (last - first + 63u) >> 6;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t unused_epoch = 0;
+    device_counter.apply(episode_base, next_counter, unused_epoch);  // (the launch state may live in device memory: common.hpp)
     // the first trip's mask words are requested before the prefix is summed
     unsigned long long word = threadIdx.x < min(words, kTripWords) ? finished_mask[(first >> 6) + threadIdx.x] : 0ull;
     if (block_counts[blockIdx.x] == 0 && !last_block) return;  // nothing finished here (uniform per workgroup)
@@ -253,6 +255,9 @@ struct BalanceSim final : mrl_sim {
     float *reward = nullptr;
     uint32_t *block_counts = nullptr, *counter = nullptr, *reset_count = nullptr;
     uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
+    mrl::LaunchStateOwner launch_state;  // parity in device memory once a caller wants to capture steps (common.hpp)
+    bool capturable() const override { return launch_state.device_mode; }
+    void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, 0, stream); }
     unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
 
     void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
@@ -262,10 +267,11 @@ struct BalanceSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
     void phase1(const int32_t *actions, hipStream_t stream) override { launch_step(actions, nullptr, 0, 0, stream); }
-    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream, bool external_base = false)
     {
+        if (launch_state.device_mode) launch_state.advance(stream);
         hipLaunchKernelGGL((mrl_balance_reset<false>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, base,
-                           0u, counter + (parity ^ 1u), reset_count, gathered);
+                           0u, counter + (parity ^ 1u), reset_count, gathered, launch_state.counter_args(counter, external_base));
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -276,7 +282,7 @@ struct BalanceSim final : mrl_sim {
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
-        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream, episode_base_dev != nullptr);
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
@@ -291,7 +297,12 @@ struct BalanceSim final : mrl_sim {
     }
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
     {
-        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (launch_state.device_mode) {  // which half is current is only known on the device
+            hipLaunchKernelGGL(mrl::set_current_counter, dim3(1), dim3(1), 0, stream, counter, launch_state.dev, next_episode);
+            MRL_HIP(hipGetLastError());
+        } else {
+            MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
         MRL_HIP(hipStreamSynchronize(stream));
     }
     void reseed_shard(uint32_t world_offset, uint32_t num_worlds_total, hipStream_t stream) override
@@ -299,7 +310,7 @@ struct BalanceSim final : mrl_sim {
         const uint32_t *none = nullptr;
         uint32_t *no_out = nullptr;
         hipLaunchKernelGGL((mrl_balance_reset<true>), dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, finished_mask, obs, block_counts, none,
-                           world_offset, no_out, no_out, mrl::GatheredCounts{});
+                           world_offset, no_out, no_out, mrl::GatheredCounts{}, mrl::DeviceCounter{});
         MRL_HIP(hipGetLastError());
         MRL_HIP(hipMemsetAsync(done, 0, sizeof(int32_t) * num_worlds, stream));
         MRL_HIP(hipMemsetAsync(reward, 0, sizeof(float) * 2 * num_worlds, stream));
@@ -367,6 +378,7 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         sim->shard_count = sim->arena.alloc<uint32_t>(1);
+        sim->launch_state.init(sim->arena);
         hipLaunchKernelGGL(fill_balance_ids, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, 0, sim->world_id, sim->agent_id, sim->active,
                            sim->mask, num_worlds);
         MRL_HIP(hipGetLastError());

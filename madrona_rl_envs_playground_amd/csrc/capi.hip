@@ -120,22 +120,22 @@ static int need_healthy(const mrl_sim *sim)
     return MRL_OK;
 }
 
-// Hanabi, Cartpole and the balance beam keep launch-to-launch state on the HOST (which half of the double-buffered episode
-// counter is current, the epoch tag and the ticket base of the single-launch step): their launches bake it into kernel
-// arguments, so a captured launch replayed later would run with stale values (workgroup indices past the grid, repeated
-// episode seeds).  Refuse to be captured instead of corrupting memory on replay.  Overcooked and Simplecooked have no such
-// state and may be captured (tests/test_gpu_overcooked.py::test_steps_captured_in_a_hip_graph_equal_eager_steps).
+// Hanabi, Cartpole and the balance beam keep launch-to-launch state on the HOST by default (which half of the
+// double-buffered episode counter is current, the epoch tag of the single-launch step): their launches bake it into kernel
+// arguments, so a captured launch replayed later would run with stale values (repeated episode seeds, a look-back that
+// accepts the previous replay's counts).  They refuse to be captured until mrl_prepare_graph_capture has moved that state
+// into device memory, where every step advances it itself.  Overcooked and Simplecooked have no such state.
 static int need_not_capturing(const mrl_sim *sim, void *hip_stream, const char *what)
 {
-    if (sim->game == MRL_GAME_OVERCOOKED || sim->game == MRL_GAME_SIMPLECOOKED || !hip_stream) return MRL_OK;
+    if (sim->capturable() || !hip_stream) return MRL_OK;
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)hip_stream, &status) != hipSuccess) {
         (void)hipGetLastError();
         return MRL_OK;
     }
     if (status == hipStreamCaptureStatusNone) return MRL_OK;
-    set_error("%s: this game's launches depend on host-side episode-counter state and cannot be captured in a HIP graph "
-              "(only Overcooked and Simplecooked steps can); issue it outside the capture", what);
+    set_error("%s: this game's launches carry host-side episode-counter state and cannot be captured in a HIP graph as they are; "
+              "call mrl_prepare_graph_capture on the simulator first (outside the capture)", what);
     return MRL_ERR_INVALID;
 }
 
@@ -318,6 +318,13 @@ int mrl_set_observation_ring(mrl_sim *sim, void *base_dev_or_null, uint64_t slot
         return MRL_ERR_INVALID;
     }
     return guarded([&] { sim->set_observation_ring(base_dev_or_null, slot_stride_bytes, num_slots); });
+}
+
+int mrl_prepare_graph_capture(mrl_sim *sim, void *hip_stream)
+{
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    mrl::DeviceGuard on(sim->device);
+    return guarded([&] { sim->prepare_graph_capture((hipStream_t)hip_stream); });
 }
 
 int mrl_set_episode_counter(mrl_sim *sim, uint32_t next_episode, void *hip_stream)

@@ -173,9 +173,9 @@ constexpr uint32_t kTripWords = 64;  // mask words (64 worlds each) the reset la
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_t chunk, float4 *__restrict__ state,
                                                              const uint32_t *__restrict__ block_counts,
                                                              const unsigned long long *__restrict__ finished_mask,
-                                                             const uint32_t *__restrict__ episode_base,
-                                                             uint32_t *__restrict__ next_counter,
-                                                             uint32_t *__restrict__ reset_count, const mrl::GatheredCounts gathered)
+                                                             const uint32_t *episode_base, uint32_t *next_counter,
+                                                             uint32_t *__restrict__ reset_count, const mrl::GatheredCounts gathered,
+                                                             const mrl::DeviceCounter device_counter)
 {
     __shared__ uint32_t s_red[2 * kBlock / 64];
     __shared__ unsigned long long s_word[kTripWords];
@@ -183,6 +183,8 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
     __shared__ uint32_t s_total;
     __shared__ uint16_t s_list[kTripWords * 64];
     const bool last_block = blockIdx.x == gridDim.x - 1;
+    uint32_t unused_epoch = 0;
+    device_counter.apply(episode_base, next_counter, unused_epoch);  // (the launch state may live in device memory: common.hpp)
     const uint32_t mine = block_counts[blockIdx.x];
     const uint32_t first = blockIdx.x * chunk, last = min(n, first + chunk);
     const uint32_t words = (last - first + 63u) >> 6;
@@ -258,11 +260,11 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
                                                                   int32_t *__restrict__ done, unsigned long long *status,
-                                                                  uint32_t epoch, const uint32_t *__restrict__ episode_base,
-                                                                  uint32_t *__restrict__ next_counter,
+                                                                  uint32_t epoch, const uint32_t *episode_base,
+                                                                  uint32_t *next_counter,
                                                                   uint32_t *__restrict__ reset_count,
                                                                   int32_t *action_out, uint64_t sample_seed, uint32_t sample_step,
-                                                                  const mrl::HealTest heal)
+                                                                  const mrl::HealTest heal, const mrl::DeviceCounter device_counter)
 {
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_wave[kBlock / 64];
@@ -270,6 +272,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     const uint32_t b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
     const bool last_block = b == gridDim.x - 1;
+    device_counter.apply(episode_base, next_counter, epoch);  // (the launch state may live in device memory: common.hpp)
     mrl::heal_test_delay(heal, b, gridDim.x, epoch);  // test hook only (uniform branch on a kernel argument)
     float4 s[kUnroll];
     int32_t a[kUnroll];
@@ -480,6 +483,9 @@ struct CartpoleSim final : mrl_sim {
     mrl::AlarmOwner alarm;
     mrl::HealTest heal;  // test hook of the healing look-back (mrl_debug_set fused_heal_test)
     uint32_t fused_grid = 0, epoch = 0;
+    mrl::LaunchStateOwner launch_state;  // parity / epoch in device memory once a caller wants to capture steps (common.hpp)
+    bool capturable() const override { return launch_state.device_mode; }
+    void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     bool scan_timed_out() const override { return alarm.raised(); }
 
     bool fused_step = false;  // mrl_debug_set fused_step: one launch with the ticketed in-kernel prefix instead of two launches
@@ -496,9 +502,10 @@ struct CartpoleSim final : mrl_sim {
     void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
     {
         epoch += 1;
+        if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
         hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions, state,
                            reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed,
-                           sample_step, heal);
+                           sample_step, heal, launch_state.counter_args(counter));
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -510,7 +517,7 @@ struct CartpoleSim final : mrl_sim {
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
         if (num_steps == 0) return;
-        if (persistent_ok) {
+        if (persistent_ok && !launch_state.device_mode) {  // (a cooperative launch cannot be captured; its counters live on the host)
             // cooperative: the runtime checks the grid against what the device can hold at once and
             // refuses it otherwise -- then, and from then on, one launch per step
             uint32_t n = num_worlds, epoch0 = ring_epoch + 1u;
@@ -547,10 +554,11 @@ struct CartpoleSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
 
-    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream, bool external_base = false)
     {
+        if (launch_state.device_mode) launch_state.advance(stream);
         hipLaunchKernelGGL(mrl_cartpole_reset, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk, state, block_counts,
-                           finished_mask, base, counter + (parity ^ 1u), reset_count, gathered);
+                           finished_mask, base, counter + (parity ^ 1u), reset_count, gathered, launch_state.counter_args(counter, external_base));
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -561,7 +569,7 @@ struct CartpoleSim final : mrl_sim {
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
-        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream, episode_base_dev != nullptr);
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
@@ -570,7 +578,12 @@ struct CartpoleSim final : mrl_sim {
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
     {
-        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (launch_state.device_mode) {  // which half is current is only known on the device
+            hipLaunchKernelGGL(mrl::set_current_counter, dim3(1), dim3(1), 0, stream, counter, launch_state.dev, next_episode);
+            MRL_HIP(hipGetLastError());
+        } else {
+            MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
         MRL_HIP(hipStreamSynchronize(stream));
     }
 
@@ -643,6 +656,7 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             }
         }
         sim->alarm.init(sim->arena);
+        sim->launch_state.init(sim->arena);
         {
             // mrl_debug_set fused_step: 0 = the library's choice by batch size, 1 = one launch, 2 = always two.  One launch
             // wins while the host's call rate is the bound, two once the GPU is: in the single launch every workgroup ends

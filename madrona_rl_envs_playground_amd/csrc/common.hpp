@@ -114,6 +114,31 @@ class AlarmOwner {
     uint32_t *host_ = nullptr;
 };
 
+// Launch-to-launch state of the games that number episodes (which half of the double-buffered episode counter is
+// current, the look-back's epoch).  By default it lives on the HOST and travels in kernel arguments -- which is why those
+// launches cannot be replayed from a HIP graph.  After mrl_prepare_graph_capture it lives HERE, in device memory: every step
+// enqueues a one-thread launch that advances it and the step's kernels read it, so a captured sequence replays correctly.
+struct LaunchState {
+    uint32_t flips;  // steps so far: the current counter is counter[flips & 1]
+    uint32_t epoch;  // tag of the single-launch step's status words
+};
+
+struct DeviceCounter {
+    const LaunchState *state = nullptr;  // nullptr: host mode, the arguments below are used as they are
+    uint32_t *counter = nullptr;         // the two halves of the episode counter
+    uint32_t external_base = 0;          // the base comes from the caller (sharded phase 2): only `next` and the epoch are derived
+    // in device mode, AFTER the step's advance launch: this step reads counter[(flips - 1) & 1] and writes counter[flips & 1]
+    __device__ __forceinline__ void apply(const uint32_t *&base, uint32_t *&next, uint32_t &epoch) const
+    {
+        if (state) {
+            const uint32_t flips = state->flips;
+            if (!external_base) base = counter + ((flips - 1u) & 1u);
+            next = counter + (flips & 1u);
+            epoch = state->epoch;
+        }
+    }
+};
+
 inline mrl_tensor_desc make_desc(void *data, int dtype, int device, std::initializer_list<int64_t> shape,
                                  std::initializer_list<int64_t> strides = {})
 {
@@ -180,6 +205,10 @@ struct mrl_sim {
     virtual uint64_t observation_bytes() const { return 0; }
     // mrl_set_observation_ring: step number k after this call writes its slab to base + (k % num_slots) * stride_bytes
     virtual void set_observation_ring(void *, uint64_t, uint32_t) {}
+    // mrl_prepare_graph_capture: from now on the launch-to-launch state lives in device memory (see LaunchState); games
+    // without such state have nothing to do.  capturable(): may this simulator's launches be captured right now?
+    virtual void prepare_graph_capture(hipStream_t) {}
+    virtual bool capturable() const { return true; }
     virtual void set_episode_counter(uint32_t, hipStream_t) {}
     virtual void reseed_shard(uint32_t, uint32_t, hipStream_t) {}
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;

@@ -67,6 +67,43 @@ __device__ __forceinline__ uint32_t lower_ranks(const GatheredCounts &g, uint32_
     return below;
 }
 
+// ---- device-resident launch state (mrl_prepare_graph_capture; common.hpp LaunchState) ----
+// one thread, enqueued in front of the kernels of a step that read the state
+__attribute__((unused)) static __global__ void advance_launch_state(LaunchState *st)
+{
+    st->flips += 1u;
+    st->epoch += 1u;
+}
+// mrl_set_episode_counter in device mode: the current half is only known on the device
+__attribute__((unused)) static __global__ void set_current_counter(uint32_t *counter, const LaunchState *st, uint32_t value)
+{
+    counter[st->flips & 1u] = value;
+}
+
+// Host side of that state, one per simulator.
+struct LaunchStateOwner {
+    LaunchState *dev = nullptr;
+    bool device_mode = false;
+    void init(DeviceArena &arena) { dev = arena.alloc<LaunchState>(1); }
+    // host mirrors -> device, once; from here on every step advances the device copy itself
+    void to_device(uint32_t parity, uint32_t epoch, hipStream_t stream)
+    {
+        if (device_mode) return;
+        const LaunchState now{parity, epoch};
+        MRL_HIP(hipMemcpyAsync(dev, &now, sizeof(now), hipMemcpyHostToDevice, stream));
+        MRL_HIP(hipStreamSynchronize(stream));
+        device_mode = true;
+    }
+    void advance(hipStream_t stream) const
+    {
+        hipLaunchKernelGGL(advance_launch_state, dim3(1), dim3(1), 0, stream, dev);
+    }
+    DeviceCounter counter_args(uint32_t *counter, bool external_base = false) const
+    {
+        return device_mode ? DeviceCounter{dev, counter, external_base ? 1u : 0u} : DeviceCounter{};
+    }
+};
+
 // whole workgroup (blockDim.x a multiple of 64, <= 1024): exclusive prefix of workgroup `block`;
 // with want_total also the sum over all workgroups.  s_red: 2 * blockDim.x / 64 words of LDS.
 __device__ __forceinline__ uint32_t scan_prefix(const uint32_t *block_counts, uint32_t num_blocks, uint32_t block,

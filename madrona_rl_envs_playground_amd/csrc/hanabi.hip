@@ -1245,7 +1245,8 @@ __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem,
 template <bool kAll, int kV>
 __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p, const uint32_t *episode_base,
                                                            uint32_t episode_base_value, uint32_t *next_counter,
-                                                           uint32_t *reset_count, const mrl::GatheredCounts gathered)
+                                                           uint32_t *reset_count, const mrl::GatheredCounts gathered,
+                                                           const mrl::DeviceCounter device_counter)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ uint32_t s_counts[kWavesPerBlock];
@@ -1262,6 +1263,8 @@ __global__ void __launch_bounds__(kBlock) mrl_hanabi_reset(const HanabiParams p,
         p.stamps[(size_t)(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+    uint32_t unused_epoch = 0;
+    if (!kAll) device_counter.apply(episode_base, next_counter, unused_epoch);  // (the launch state may live in device memory: common.hpp)
     uint32_t base = kAll ? episode_base_value : *episode_base, all_ranks = 0;
     const uint32_t counter_now = base;
     if (!kAll && gathered.counts) base += mrl::lower_ranks(gathered, &all_ranks);  // sharded batch: the ranks below come first
@@ -1332,7 +1335,7 @@ __global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_e
 mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t heal_mod, uint32_t pair_stride,
                       const HanabiParams p0,
                       unsigned long long *status, uint32_t epoch, const uint32_t *episode_base, uint32_t *next_counter,
-                      uint32_t *reset_count, uint32_t *heal_seen)
+                      uint32_t *reset_count, uint32_t *heal_seen, const mrl::DeviceCounter device_counter)
 {
     constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
@@ -1360,6 +1363,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     const mrl::HealTest heal{heal_mod, heal_seen};
     const uint32_t N = p.num_worlds;
     const bool last_block = bid == gridDim.x - 1;
+    if (scan_wave || heal_mod) device_counter.apply(episode_base, next_counter, epoch);  // (the launch state may live in device memory: common.hpp)
     if (threadIdx.x == 0) s_ready = 0u;
     if (heal_mod) mrl::heal_test_delay(heal, bid, gridDim.x, epoch);  // test hook only (uniform branch on a preloaded argument)
 
@@ -1687,7 +1691,10 @@ struct HanabiSim final : mrl_sim {
     uint32_t pair_stride = 4;  // phase A of the single-launch step by four leader waves (see the kernel); mrl_debug_set hanabi.pairing
     uint32_t epoch = 0;
     bool fused = false;
+    mrl::LaunchStateOwner launch_state;  // parity / epoch in device memory once a caller wants to capture steps (common.hpp)
     bool scan_timed_out() const override { return alarm.raised(); }
+    bool capturable() const override { return launch_state.device_mode; }
+    void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
 
     void step(const int32_t *actions, hipStream_t stream) override
     {
@@ -1700,10 +1707,12 @@ struct HanabiSim final : mrl_sim {
         epoch += 1;
         const uint32_t *base = counter + parity;
         uint32_t *next = counter + (parity ^ 1u);
+        if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
+        const mrl::DeviceCounter dc = launch_state.counter_args(counter);
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
         }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -1739,7 +1748,7 @@ struct HanabiSim final : mrl_sim {
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
         if (num_steps == 0) return;
-        if (persistent_ok) {
+        if (persistent_ok && !launch_state.device_mode) {  // (a cooperative launch cannot be captured; its counters live on the host)
             bool launched;
             switch (variant) {
             case 2: launched = launch_rollout<2>(num_steps, seed, first_step, stream); break;
@@ -1772,20 +1781,22 @@ struct HanabiSim final : mrl_sim {
         MRL_HIP(hipGetLastError());
     }
 
-    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream)
+    void launch_reset(const uint32_t *base, const mrl::GatheredCounts &gathered, hipStream_t stream, bool external_base = false)
     {
+        if (launch_state.device_mode) launch_state.advance(stream);
+        const mrl::DeviceCounter dc = launch_state.counter_args(counter, external_base);
         switch (variant) {
         case 2:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 2>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count, gathered);
+                               counter + (parity ^ 1u), reset_count, gathered, dc);
             break;
         case 1:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 1>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count, gathered);
+                               counter + (parity ^ 1u), reset_count, gathered, dc);
             break;
         default:
             hipLaunchKernelGGL((mrl_hanabi_reset<false, 0>), dim3(grid), dim3(kBlock), 0, stream, params, base, 0u,
-                               counter + (parity ^ 1u), reset_count, gathered);
+                               counter + (parity ^ 1u), reset_count, gathered, dc);
             break;
         }
         MRL_HIP(hipGetLastError());
@@ -1798,7 +1809,7 @@ struct HanabiSim final : mrl_sim {
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
     {
-        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream);
+        launch_reset(episode_base_dev ? episode_base_dev : counter + parity, mrl::GatheredCounts{}, stream, episode_base_dev != nullptr);
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
@@ -1807,7 +1818,12 @@ struct HanabiSim final : mrl_sim {
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
     {
-        MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        if (launch_state.device_mode) {  // which half is current is only known on the device
+            hipLaunchKernelGGL(mrl::set_current_counter, dim3(1), dim3(1), 0, stream, counter, launch_state.dev, next_episode);
+            MRL_HIP(hipGetLastError());
+        } else {
+            MRL_HIP(hipMemcpyAsync(counter + parity, &next_episode, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        }
         MRL_HIP(hipStreamSynchronize(stream));
     }
 
@@ -1816,9 +1832,9 @@ struct HanabiSim final : mrl_sim {
         const uint32_t *none = nullptr;
         uint32_t *no_out = nullptr;
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_reset<true, 2>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_reset<true, 1>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_reset<true, 2>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}, mrl::DeviceCounter{}); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_reset<true, 1>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}, mrl::DeviceCounter{}); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_reset<true, 0>), dim3(grid), dim3(kBlock), 0, stream, params, none, world_offset, no_out, no_out, mrl::GatheredCounts{}, mrl::DeviceCounter{}); break;
         }
         MRL_HIP(hipGetLastError());
         set_episode_counter(num_worlds_total, stream);
@@ -1956,6 +1972,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
         sim->counter = sim->arena.alloc<uint32_t>(2);
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         sim->alarm.init(sim->arena);
+        sim->launch_state.init(sim->arena);
         sim->status = sim->arena.alloc<unsigned long long>(sim->grid);
         {
             // mrl_debug_set fused_step: 0 = the library's choice (one launch whenever a workgroup owns one sub-block),

@@ -258,6 +258,12 @@ class _Simulator:
             raise ValueError(f"out must be a contiguous int8 tensor on cuda:{self.gpu_id}")
         _lib.check(self._L.mrl_set_observation_output(self._handle, out.data_ptr(), out.numel()))
 
+    def prepare_graph_capture(self):
+        """Makes this simulator's steps capturable in a HIP graph (``torch.cuda.graph``): Hanabi, Cartpole and the balance beam
+        move their launch-to-launch counter state into device memory (``mrl_prepare_graph_capture``; one extra one-thread
+        launch per step from then on); nothing to do for Overcooked and Simplecooked.  Call it outside the capture."""
+        _lib.check(self._L.mrl_prepare_graph_capture(self._handle, _stream_ptr(self.gpu_id)))
+
     def set_observation_ring(self, ring):
         """``ring``: an int8 CUDA tensor (T, N, P, H, W, F) whose slots ``ring[s]`` are contiguous -- a rollout buffer.  Step
         number k from this call on writes its observations to ``ring[k % T]``, whether it is a call of its own or step k of

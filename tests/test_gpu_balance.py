@@ -110,3 +110,30 @@ def test_env_wrapper(hip_lib):
         ends += int(done.sum())
     assert ends >= 4 * n  # at most three steps per episode
     env.close()
+
+
+def test_steps_captured_in_a_hip_graph_after_prepare(hip_lib):
+    """A third of the worlds re-seed every step: a captured sequence of three steps replayed 30 times on a simulator prepared
+    with mrl_prepare_graph_capture equals 90 steps issued one by one on an ordinary one."""
+    from madrona_rl_envs_playground_amd.simulators import BalanceBeamSimulator, ExecMode
+    n = 50000
+    eager, graphed = BalanceBeamSimulator(ExecMode.CUDA, 0, n), BalanceBeamSimulator(ExecMode.CUDA, 0, n)
+    graphed.prepare_graph_capture()
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    acts = [torch.randint(0, 4, (2, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for a in acts:
+                graphed.step_with_actions(a)
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(30):
+        graph.replay()
+        for a in acts:
+            eager.step_with_actions(a)
+        for name in ("observation_tensor", "done_tensor", "reward_tensor", "reset_count_tensor"):
+            assert torch.equal(getattr(eager, name)().to_torch(), getattr(graphed, name)().to_torch()), f"{name} differs after replay {rep}"
+    eager.close()
+    graphed.close()

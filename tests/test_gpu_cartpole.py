@@ -220,9 +220,50 @@ def test_scan_timeout_is_an_error_not_a_silent_flag(hip_lib):
     ok.close()
 
 
+@pytest.mark.parametrize("n,fused", [(3000, 1), (300001, 1), (300001, 2)], ids=["one_launch_3000", "one_launch_300001", "two_launches_300001"])
+def test_steps_captured_in_a_hip_graph_after_prepare(n, fused, hip_lib):
+    """mrl_prepare_graph_capture moves the launch-to-launch state (which half of the episode counter is current, the look-back's
+    epoch) into device memory; every step then advances it with a one-thread launch of its own, so a captured sequence of an
+    ODD number of steps replayed several times -- and eager steps in between -- equals the same steps issued one by one on an
+    ordinary simulator."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    with debug_knobs({"fused_step": fused}):
+        eager, graphed = make(n), make(n)
+    graphed.prepare_graph_capture()
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    acts = [torch.randint(0, 2, (n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for a in acts:
+                graphed.step_with_actions(a)
+    torch.cuda.current_stream().wait_stream(side)
+    finished = 0
+    for rep in range(40):
+        graph.replay()
+        for a in acts:
+            eager.step_with_actions(a)
+        if rep % 3 == 0:  # an eager step on the prepared simulator between two replays
+            graphed.step_with_actions(acts[1])
+            eager.step_with_actions(acts[1])
+        for name in ("observation_tensor", "reset_tensor", "reward_tensor", "reset_count_tensor"):
+            assert torch.equal(getattr(eager, name)().to_torch(), getattr(graphed, name)().to_torch()), f"{name} differs after replay {rep}"
+        finished += int(eager.reset_count_tensor().to_torch().item())
+    assert finished > 0
+    # the device-side policy on a prepared simulator: one launch per step, same stream of draws
+    graphed.rollout_random(7, seed=3, first_step=0)
+    eager.rollout_random(7, seed=3, first_step=0)
+    assert torch.equal(eager.observation_tensor().to_torch(), graphed.observation_tensor().to_torch())
+    eager.close()
+    graphed.close()
+
+
 def test_step_refuses_graph_capture(hip_lib):
     """Cartpole / Hanabi / balance launches carry host-side counter state in their arguments: a replayed
-    capture would run with stale values, so the entry points refuse a capturing stream instead (MRL_ERR_INVALID)."""
+    capture would run with stale values, so -- until mrl_prepare_graph_capture has been called -- the entry points refuse a
+    capturing stream (MRL_ERR_INVALID)."""
     from madrona_rl_envs_playground_amd._lib import MrlError
     sim = make(2048)
     a = torch.zeros((2048, 1), dtype=torch.int32, device="cuda")

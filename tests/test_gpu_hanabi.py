@@ -313,3 +313,35 @@ def test_phase_a_pairings_agree(n, hip_lib):
     assert finished > 0
     for s in sims:
         s.close()
+
+
+@pytest.mark.parametrize("n,fused", [(9000, 1), (70001, 1), (70001, 2)], ids=["one_launch_9000", "one_launch_70001", "two_launches_70001"])
+def test_steps_captured_in_a_hip_graph_after_prepare(n, fused, hip_lib):
+    """mrl_prepare_graph_capture: the episode counter's parity and the look-back's epoch live in device memory from then on, so
+    a captured sequence of three steps (legal moves drawn by the step kernel from a fixed stream) replayed 25 times -- with
+    eager steps in between -- equals the same calls issued one by one on an ordinary simulator."""
+    with debug_knobs({"fused_step": fused, "hanabi.no_persistent": 1}):
+        eager, graphed = make(FULL, n), make(FULL, n)
+    graphed.prepare_graph_capture()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            graphed.rollout_random(3, seed=21, first_step=100)
+    torch.cuda.current_stream().wait_stream(side)
+    names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor", "done_tensor",
+             "game_tensor", "reset_count_tensor", "action_tensor"]
+    finished = 0
+    for rep in range(25):
+        graph.replay()
+        eager.rollout_random(3, seed=21, first_step=100)
+        if rep % 4 == 0:
+            graphed.rollout_random(1, seed=5, first_step=rep)
+            eager.rollout_random(1, seed=5, first_step=rep)
+        for name in names:
+            assert torch.equal(getattr(eager, name)().to_torch(), getattr(graphed, name)().to_torch()), f"{name} differs after replay {rep}"
+        finished += int(eager.reset_count_tensor().to_torch().item())
+    assert finished > 0
+    eager.close()
+    graphed.close()
