@@ -1,14 +1,16 @@
-"""Per-wave phase timeline of mrl_hanabi_step (diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag)."""
+"""Per-wave phase timeline of the TWO-LAUNCH Hanabi step, mrl_hanabi_step + mrl_hanabi_reset (what the sharded path runs;
+tools/stamps_hanabi_fused.py is the single launch).  Diagnostic build: make -C madrona_rl_envs_playground_amd/csrc diag."""
 import os, sys, torch, numpy as np
 _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import _lib
-_lib.debug_set("stamps", 1)
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
-                      max_information_tokens=8, max_life_tokens=3)
+with _lib.debug_knobs({"stamps": 1, "fused_step": 2}):
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                          max_information_tokens=8, max_life_tokens=3)
+assert sim.kernel_name == "mrl_hanabi_step", sim.kernel_name
 mask, act = sim.action_mask_tensor().to_torch(), sim.action_tensor().to_torch()
 for i in range(150):
     act.copy_((torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True).to(torch.int32))

@@ -5,13 +5,14 @@ _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("MRL_ENVS_LIB", os.path.join(_REPO, "madrona_rl_envs_playground_amd", "diag", "libmrl_envs_diag.so"))
 sys.path.insert(0, _REPO)
 from madrona_rl_envs_playground_amd import _lib
-_lib.debug_set("stamps", 1)
-if len(sys.argv) > 2:
-    _lib.debug_set("hanabi.pairing", int(sys.argv[2]))
 from madrona_rl_envs_playground_amd.simulators import ExecMode, HanabiSimulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
-                      max_information_tokens=8, max_life_tokens=3)
+knobs = {"stamps": 1}
+if len(sys.argv) > 2:
+    knobs["hanabi.pairing"] = int(sys.argv[2])  # 4 / 1 / 0: phase-A pairing; +256: workgroups 2k and 2k + 1 swap their worlds
+with _lib.debug_knobs(knobs):
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                          max_information_tokens=8, max_life_tokens=3)
 assert sim.kernel_name == "mrl_hanabi_step_fused", sim.kernel_name
 mask, act = sim.action_mask_tensor().to_torch(), sim.action_tensor().to_torch()
 for i in range(150):
