@@ -203,6 +203,23 @@ def run(args):
         env.n_step(rand)
     torch.cuda.synchronize()
     dt_env = time.perf_counter() - t1
+    # the row's own piece without the policy in the way: env step + getting the ego's observation into the buffer, us per step
+    ring = torch.empty((8,) + tuple(env.static_world_major_observations.shape), dtype=torch.int8, device="cuda")
+    copies = torch.empty((8, n, env.width, env.height, 5 * env.num_players + 16), dtype=torch.int8, device="cuda")
+
+    def timed(fn):
+        for i in range(10):
+            fn(i)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(T):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / T * 1e6
+    insert_us = {"step_into_slot": timed(lambda i: env.n_step(rand, out=ring[i % 8])),
+                 "step_then_clone_insert": timed(lambda i: copies[i % 8].copy_(env.n_step(rand)[0][env.ego_ind].obs))}
+    env.n_step(rand)  # hand the output back to the simulator's own tensor
+    del ring, copies
     per_rank = all_ranks(mine)
     per_rank_env = all_ranks(dt_env)
     if rank == 0:
@@ -213,7 +230,8 @@ def run(args):
                "loop_env_steps_per_s": n * world_size * T / slowest, "loop_ms_per_step": slowest / T * 1e3,
                "per_rank_loop_env_steps_per_s": [n * T / x for x in per_rank],
                "sum_of_ranks_env_steps_per_s": sum(n * T / x for x in per_rank),
-               "env_n_step_only_steps_per_s": sum(n * T / x for x in per_rank_env), "env_n_step_only_ms": max(per_rank_env) / T * 1e3}
+               "env_n_step_only_steps_per_s": sum(n * T / x for x in per_rank_env), "env_n_step_only_ms": max(per_rank_env) / T * 1e3,
+               "env_step_plus_buffer_insert_us": insert_us}
         if use_dist:
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend, "rehearsal_on_one_gpu": bool(rehearse)}
         print(json.dumps(out), flush=True)
