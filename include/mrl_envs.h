@@ -293,6 +293,17 @@ int mrl_scan_timed_out(const mrl_sim *sim);
  * reference wrappers make (static_actions.copy_, envs/overcooked_env.py:107). */
 int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_stream);
 
+/* Several simulators stepped by ONE launch: any mix of Overcooked layouts, sizes, player counts and world counts on one device
+ * (the reference's Config holds a single terrain, src/overcooked_env/sim.hpp:44-57, so a curriculum over several layouts is
+ * several simulators there, each with a step call of its own).  The grid is the concatenation of the simulators' grids and
+ * every workgroup runs its simulator's step on that simulator's parameters, which travel in the kernel arguments.  Same
+ * results as one mrl_step_with_actions per simulator (actions_dev_or_null == NULL or an entry NULL: that simulator's
+ * ACTION tensor).  At most 8 simulators per call; the generic step kernel is used, so large single-layout batches are
+ * better off with their own, specialised launch -- this is for many small sub-batches, where the launches are what
+ * costs.  Overcooked only (MRL_ERR_INVALID otherwise, and for the few-worlds-of-a-large-layout configurations whose
+ * workgroups share one state copy). */
+int mrl_step_many(mrl_sim *const *sims, uint32_t count, const int32_t *const *actions_dev_or_null, void *hip_stream);
+
 /* The same with the caller's actions as int64 (same shape and layout): what the reference's harness hands
  * `env.n_step` (scripts/overcooked_example.py:99-106: `torch.randint_like` of a long tensor), which the reference
  * wrapper narrows with a gather + copy kernel per step (envs/overcooked_env.py:104-107).  Here the step kernel reads

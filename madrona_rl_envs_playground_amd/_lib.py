@@ -30,7 +30,7 @@ SYMBOLS = [
     "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
     "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
-    "mrl_step_phase2_gathered", "mrl_set_observation_output", "mrl_set_observation_ring", "mrl_prepare_graph_capture",
+    "mrl_step_phase2_gathered", "mrl_set_observation_output", "mrl_set_observation_ring", "mrl_prepare_graph_capture", "mrl_step_many",
 ]
 ABI_VERSION = 3  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
@@ -108,6 +108,7 @@ def lib():
     L.mrl_step.argtypes = [vp, vp]
     L.mrl_step_with_actions.argtypes = [vp, vp, vp]
     L.mrl_step_with_actions_i64.argtypes = [vp, vp, vp]
+    L.mrl_step_many.argtypes = [ctypes.POINTER(vp), u32, ctypes.POINTER(vp), vp]
     L.mrl_step_phase1.argtypes = [vp, vp, vp]
     L.mrl_step_phase2.argtypes = [vp, vp, vp]
     L.mrl_step_phase2_gathered.argtypes = [vp, vp, u32, u32, vp]

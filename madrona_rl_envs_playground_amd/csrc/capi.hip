@@ -238,6 +238,19 @@ int mrl_step_with_actions(mrl_sim *sim, const int32_t *actions_dev, void *hip_st
     return guarded([&] { sim->step(actions_dev, (hipStream_t)hip_stream); });
 }
 
+int mrl_step_many(mrl_sim *const *sims, uint32_t count, const int32_t *const *actions_dev_or_null, void *hip_stream)
+{
+    if (!sims && count) {
+        mrl::set_error("mrl_step_many: null simulator list");
+        return MRL_ERR_INVALID;
+    }
+    for (uint32_t k = 0; k < count; k++)
+        if (int rc = mrl::need_healthy(sims[k])) return rc;
+    if (count == 0) return MRL_OK;
+    mrl::DeviceGuard on(sims[0]->device);
+    return guarded([&] { mrl::step_many_overcooked(sims, count, actions_dev_or_null, (hipStream_t)hip_stream); });
+}
+
 int mrl_step_with_actions_i64(mrl_sim *sim, const int64_t *actions_dev, void *hip_stream)
 {
     if (int rc = mrl::need_healthy(sim)) return rc;

@@ -228,4 +228,6 @@ mrl_sim *create_simplecooked(const mrl_overcooked_config *cfg, int gpu_id, uint3
 mrl_sim *create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t num_worlds);
 mrl_sim *create_cartpole(int gpu_id, uint32_t num_worlds);
 mrl_sim *create_balance(int gpu_id, uint32_t num_worlds);
+// several Overcooked simulators' steps as one launch (mrl_step_many); actions_or_null[k] == nullptr: simulator k's ACTION tensor
+void step_many_overcooked(mrl_sim *const *sims, uint32_t count, const int32_t *const *actions_or_null, hipStream_t stream);
 }  // namespace mrl

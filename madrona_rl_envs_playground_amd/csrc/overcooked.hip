@@ -134,6 +134,7 @@ struct StepParams {
     // ring_stride bytes apart from `obs`; ring_slots <= 1: every step writes `obs`
     uint64_t ring_stride;
     uint32_t ring_slots, ring_first;
+    uint32_t pair_exchange;  // mrl_step_many: two players and the pair-exchange (DPP) transition is this simulator's (not forced generic)
 };
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -923,8 +924,10 @@ __device__ __forceinline__ uint32_t load_action(const StepParams &p, size_t at)
     return *reinterpret_cast<const uint32_t *>(base + (at << (wide ? 3 : 2)));
 }
 
+// `block`: the workgroup's index among those of THIS simulator (blockIdx.x, except under mrl_overcooked_step_many, where
+// one grid covers the workgroups of several simulators)
 template <bool kInit, int kP, bool kPlain = false>
-__device__ __forceinline__ void step_body(const StepParams &p)
+__device__ __forceinline__ void step_body(const StepParams &p, const uint32_t block)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -961,7 +964,7 @@ __device__ __forceinline__ void step_body(const StepParams &p)
     // give each XCD one contiguous range of worlds (neighbouring groups share
     // cache lines of the state arrays and of the observation slab; keep them in one L2).
     const uint32_t per_xcd = p.per_xcd;
-    const uint32_t logical_block = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t logical_block = (block & 7u) * per_xcd + (block >> 3);
     const uint32_t w0 = p.share ? logical_block : (logical_block * kWavesPerBlock + wib) * p.wpw;
     const uint32_t nw = w0 < p.num_worlds ? min(p.wpw, p.num_worlds - w0) : 0u;
 
@@ -1504,7 +1507,34 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step_team(const StepPar
 template <bool kInit, int kP, bool kPlain = false>
 __global__ void __launch_bounds__(kBlock) mrl_overcooked_step(const StepParams p)
 {
-    step_body<kInit, kP, kPlain>(p);
+    step_body<kInit, kP, kPlain>(p, blockIdx.x);
+}
+
+// Several simulators -- any mix of layouts, sizes and player counts -- stepped by ONE launch (mrl_step_many): the grid is
+// the concatenation of their grids, a workgroup finds the simulator it belongs to and runs that simulator's step on
+// that simulator's parameters, which travel by value in the kernel arguments (328 bytes each: no table in device memory
+// to keep up to date).  The step itself is the generic one -- a kernel specialised for one layout size cannot serve
+// several -- so a big single-layout batch is better off with its own launch; this is for many small sub-batches, where
+// the launches, not the worlds, are what costs.
+constexpr int kMaxMany = 8;
+struct ManyParams {
+    StepParams sim[kMaxMany];
+    uint32_t first_block[kMaxMany + 1];  // workgroups of simulator k: first_block[k] .. first_block[k + 1]
+    uint32_t count;
+};
+static_assert(sizeof(ManyParams) <= 3072, "the parameters of a many-simulator launch travel in the kernel argument segment (4 KB)");
+
+__global__ void __launch_bounds__(kBlock) mrl_overcooked_step_many(const ManyParams m)
+{
+    uint32_t k = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxMany; j++) k += ((uint32_t)j < m.count && blockIdx.x >= m.first_block[j]) ? 1u : 0u;
+    const StepParams &p = m.sim[k];
+    const uint32_t block = blockIdx.x - m.first_block[k];
+    if (p.P == 2u && p.pair_exchange)
+        step_body<false, 2, false>(p, block);
+    else
+        step_body<false, 0, false>(p, block);
 }
 
 // Per-wave LDS offsets of the single-pass, two-player, private-constants configuration: the same formulas as
@@ -1611,7 +1641,7 @@ __global__ void __launch_bounds__(kBlock) mrl_overcooked_step_fixed(MRL_HOT_ARGS
 {
     StepParams q = fixed_params<kC, kW, kWidth, kPots, kHold>(p);
     take_hot_args<kI64>(q, MRL_HOT_PASS);
-    step_body<false, 2, kPlain>(q);
+    step_body<false, 2, kPlain>(q, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2053,6 +2083,18 @@ struct OvercookedSim final : mrl_sim {
         ring_pos += steps;
         if (first) *first = at;
         return ring_base + (size_t)at * ring_stride;
+    }
+
+    // this step's parameters as the generic step kernel takes them (mrl_step_many)
+    StepParams generic_step_params(const int32_t *actions)
+    {
+        StepParams a = params;
+        a.actions = actions ? actions : action;
+        a.obs = take_slots(1, nullptr);
+        a.ring_slots = 1;
+        a.per_xcd = grid >> 3;
+        a.pair_exchange = (a.P == 2 && !generic) ? 1u : 0u;
+        return a;
     }
 
     void launch(bool init, const int32_t *actions, hipStream_t stream)
@@ -2633,4 +2675,43 @@ mrl_sim *mrl::create_overcooked(const mrl_overcooked_config *cfg, int gpu_id, ui
         throw;
     }
     return sim;
+}
+
+// mrl_step_many (include/mrl_envs.h): the simulators' steps as ONE launch of mrl_overcooked_step_many
+void mrl::step_many_overcooked(mrl_sim *const *sims, uint32_t count, const int32_t *const *actions_or_null, hipStream_t stream)
+{
+    if (count == 0) return;
+    if (count > (uint32_t)kMaxMany) {
+        set_error("mrl_step_many: at most %d simulators per launch, got %u", kMaxMany, count);
+        throw HipError{MRL_ERR_INVALID};
+    }
+    ManyParams m{};
+    uint32_t blocks = 0, lds = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        auto *sim = static_cast<OvercookedSim *>(sims[k]);
+        if (sims[k]->game != MRL_GAME_OVERCOOKED || sims[k]->device != sims[0]->device || sim->params.team) {
+            set_error("mrl_step_many: simulator %u is not an Overcooked simulator on device %d that the generic step kernel can run "
+                      "(few worlds of a large layout share one state copy per workgroup: step those on their own)", k, sims[0]->device);
+            throw HipError{MRL_ERR_INVALID};
+        }
+        for (uint32_t j = 0; j < k; j++)
+            if (sims[j] == sims[k]) {
+                set_error("mrl_step_many: simulator %u is listed twice", k);
+                throw HipError{MRL_ERR_INVALID};
+            }
+        m.first_block[k] = blocks;
+        blocks += sim->grid;
+        lds = std::max(lds, sim->lds_bytes);
+    }
+    m.first_block[count] = blocks;
+    m.count = count;
+    for (uint32_t k = 0; k < count; k++)
+        m.sim[k] = static_cast<OvercookedSim *>(sims[k])->generic_step_params(actions_or_null ? actions_or_null[k] : nullptr);
+    static uint32_t lds_allowed = 65536;
+    if (lds > lds_allowed) {
+        MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step_many), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(mrl_overcooked_step_many, dim3(blocks), dim3(kBlock), lds, stream, m);
+    MRL_HIP(hipGetLastError());
 }

@@ -372,6 +372,22 @@ class OvercookedSimulator(_Simulator):
     def state_timestep_tensor(self): return self._tensor(13)
 
 
+def step_many(sims, actions=None):
+    """One launch for several ``OvercookedSimulator``s on one GPU -- any mix of layouts and world counts (``mrl_step_many``).
+    ``actions``: None (every simulator's ACTION tensor) or one int32 tensor per simulator (an entry may be None)."""
+    if not sims:
+        return
+    if any(type(s) is not OvercookedSimulator for s in sims):
+        raise ValueError("step_many takes OvercookedSimulator instances")
+    handles = (ctypes.c_void_p * len(sims))(*[s._handle for s in sims])
+    ptrs = None
+    if actions is not None:
+        if len(actions) != len(sims):
+            raise ValueError("one action tensor (or None) per simulator")
+        ptrs = (ctypes.c_void_p * len(sims))(*[None if a is None else s._action_pointer(a) for s, a in zip(sims, actions)])
+    _lib.check(sims[0]._L.mrl_step_many(handles, len(sims), ptrs, _stream_ptr(sims[0].gpu_id)))
+
+
 class SimplecookedSimulator(OvercookedSimulator):
     """Signature of src/overcooked2_env/bindings.cpp:14-71 ("Simplecooked": the world the reference's trainer
     uses, train/env_utils.py:3).  Same keyword arguments and tensor getters as ``OvercookedSimulator``; terrain

@@ -282,14 +282,16 @@ def test_mappo_rollout_loop_starts_its_own_ranks(mode, hip_lib):
     assert out["observations"].startswith("written into the buffer slot")
 
 
-@pytest.mark.parametrize("graph", [False, True], ids=["forked_streams", "one_captured_graph"])
-def test_several_layouts_as_one_batch(graph, hip_lib):
-    """OvercookedMultiLayout: the five standard layouts stepped side by side on their own streams give, layout by
-    layout, what five separate envs give -- issued call by call, and as ONE captured HIP graph replayed per step."""
+@pytest.mark.parametrize("mode", ["forked_streams", "graph", "one_launch", "sequential", "auto"])
+def test_several_layouts_as_one_batch(mode, hip_lib):
+    """OvercookedMultiLayout: the five standard layouts stepped side by side give, layout by layout, what five separate envs
+    give -- on forked streams call by call, as ONE captured HIP graph replayed per step, and as ONE kernel launch
+    (mrl_step_many: the grid is the concatenation of the five simulators' grids)."""
     from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
     from madrona_rl_envs_playground_amd.envs.multi_layout import OvercookedMultiLayout
     counts = [300, 77, 512, 64, 129]
-    multi = OvercookedMultiLayout(STANDARD, counts, 0, horizon=35, graph=graph)
+    multi = OvercookedMultiLayout(STANDARD, counts, 0, horizon=35, mode=mode)
+    assert multi.mode == ("one_launch" if mode == "auto" else mode)
     singles = [OvercookedMadrona(name, n, 0, horizon=35) for name, n in zip(STANDARD, counts)]
     gen = torch.Generator(device="cuda").manual_seed(21)
     for _ in range(80):
@@ -300,6 +302,51 @@ def test_several_layouts_as_one_batch(graph, hip_lib):
             mobs, mrew, mdone, _ = got[k]
             assert all(torch.equal(a.obs, b.obs) for a, b in zip(obs, mobs)), STANDARD[k]
             assert torch.equal(rew, mrew) and torch.equal(done, mdone)
+    if multi.mode == "one_launch":  # int32 actions are read where they are
+        for _ in range(20):
+            acts32 = [torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda", generator=gen) for n in counts]
+            got = multi.n_step(acts32)
+            for k, env in enumerate(singles):
+                obs, rew, done, _ = env.n_step(acts32[k])
+                assert all(torch.equal(a.obs, b.obs) for a, b in zip(obs, got[k][0])) and torch.equal(rew, got[k][1])
     multi.close()
     for env in singles:
         env.close()
+
+
+def test_one_launch_for_several_simulators_of_any_shape(hip_lib, oracle_lib):
+    """mrl_step_many: eight simulators -- different layouts, player counts (2, 3, 4), world counts from 5 to 4099, horizons --
+    stepped by one launch per step, each against its own oracle; bad lists are refused."""
+    from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, step_many
+    specs = [("cramped_room", None, 4099, 30), ("counter_circuit", None, 1000, 50), ("multiplayer_schelling", None, 130, 25), ("cramped_room", None, 5, 400),
+             ("asymmetric_advantages", None, 777, 40), ("forced_coordination", None, 64, 33), ("counter_circuit", None, 33, 20), ("coordination_ring", None, 3001, 45)]
+    sims, orcs, ps = [], [], []
+    for name, cap, n, horizon in specs:
+        params = layouts.get_base_layout_params(name, horizon, max_num_players=cap)
+        sims.append(OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params))
+        orcs.append(oracle_lib.OvercookedOracle(params, n, num_threads=8))
+        ps.append(params["num_players"])
+    assert len({p for p in ps}) >= 2
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    for t in range(70):
+        acts = [torch.randint(0, 8, (P, spec[2], 1), dtype=torch.int32, device="cuda", generator=gen).clamp_(max=5) for P, spec in zip(ps, specs)]
+        step_many(sims, acts)
+        for k, (sim, orc) in enumerate(zip(sims, orcs)):
+            orc.step(acts[k][:, :, 0].cpu().numpy())
+            got = sim.observation_world_major_tensor().to_torch().cpu().numpy().astype(np.uint8)
+            assert np.array_equal(got.reshape(orc.obs.shape), orc.obs), f"{specs[k][0]}: observations differ at step {t}"
+            assert np.array_equal(sim.reward_tensor().to_torch().cpu().numpy(), orc.reward) and np.array_equal(sim.done_tensor().to_torch().cpu().numpy(), orc.done)
+    with pytest.raises(Exception, match="twice"):
+        step_many([sims[0], sims[0]])
+    # few worlds of a large layout run one state copy per workgroup (another kernel): refused, with a message that says so
+    team = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=500, **layouts.get_base_layout_params("many_player_layout", 60, max_num_players=4))
+    with pytest.raises(Exception, match="share one state copy"):
+        step_many([sims[0], team])
+    team.close()
+    with pytest.raises(ValueError):
+        step_many([sims[0], CartpoleSimulator(ExecMode.CUDA, 0, 8)])
+    with pytest.raises(Exception, match="at most"):
+        extra = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=4, **layouts.get_base_layout_params("cramped_room", 10))
+        step_many(sims + [extra])
+    for sim in sims:
+        sim.close()
