@@ -100,6 +100,36 @@ __device__ __forceinline__ void shift_history(Row &r, int32_t own, int32_t partn
     r.x[2 * kTime] = time;
 }
 
+// One world's step on its two rows: moves, history, reward, termination (sim.cpp:76-151).  Pure in (rows, actions):
+// the single-launch step's healing look-back re-runs it on another workgroup's inputs to learn how many of its worlds finish.
+__device__ __forceinline__ bool move_world(Row &r0, Row &r1, int32_t a0, int32_t a1, float &rew)
+{
+    const int32_t loc0 = r0.x[0] - kBuffer + move_of(a0), loc1 = r1.x[0] - kBuffer + move_of(a1);
+    const int32_t time = r0.x[2 * kTime] - 1;
+    shift_history(r0, loc0, loc1, time);
+    shift_history(r1, loc1, loc0, time);
+    // checkDone (sim.cpp:114-151): double arithmetic, rounded to float once
+    const int32_t gap = loc0 > loc1 ? loc0 - loc1 : loc1 - loc0;
+    rew = (float)(loc0 == loc1 ? 1.0 : -gap * 0.2);
+    bool over = false;
+    if (loc0 < 0 || loc0 >= kSpaces || loc1 < 0 || loc1 >= kSpaces) {
+        over = true;
+        rew = (float)(-kSpaces * (time + 1) * 0.2);
+    }
+    return over || time == 0;
+}
+
+__device__ __forceinline__ void actions_of(const int32_t *action, uint32_t n, uint32_t w, bool sampled, uint64_t seed, uint32_t step, int32_t &a0, int32_t &a1)
+{
+    if (sampled) {  // uniform over the four moves, drawn here (include/mrl_envs.h: mrl_rollout_random)
+        a0 = (int32_t)mrl::scale(mrl::policy_hash(seed, step, w, 0), 4u);
+        a1 = (int32_t)mrl::scale(mrl::policy_hash(seed, step, w, 1), 4u);
+    } else {
+        a0 = action[w];
+        a1 = action[(size_t)n + w];
+    }
+}
+
 // workgroup b owns worlds [b*chunk, (b+1)*chunk), chunk a multiple of kBlock
 __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t chunk, const int32_t *action,  // (no __restrict__: mrl_rollout_random passes the ACTION tensor as action_out too)
                                                            int32_t *__restrict__ obs, float *__restrict__ reward,
@@ -119,27 +149,13 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step(uint32_t n, uint32_t 
         if (w < last) {
         Row r0 = load_row(obs, n, 0, w), r1 = load_row(obs, n, 1, w);
         int32_t a0, a1;
-        if (action_out) {  // uniform over the four moves, drawn here (include/mrl_envs.h: mrl_rollout_random)
-            a0 = (int32_t)mrl::scale(mrl::policy_hash(sample_seed, sample_step, w, 0), 4u);
-            a1 = (int32_t)mrl::scale(mrl::policy_hash(sample_seed, sample_step, w, 1), 4u);
+        actions_of(action, n, w, action_out != nullptr, sample_seed, sample_step, a0, a1);
+        if (action_out) {
             action_out[w] = a0;
             action_out[(size_t)n + w] = a1;
-        } else {
-            a0 = action[w];
-            a1 = action[(size_t)n + w];
         }
-        const int32_t loc0 = r0.x[0] - kBuffer + move_of(a0), loc1 = r1.x[0] - kBuffer + move_of(a1);
-        const int32_t time = r0.x[2 * kTime] - 1;
-        shift_history(r0, loc0, loc1, time);
-        shift_history(r1, loc1, loc0, time);
-        // checkDone (sim.cpp:114-151): double arithmetic, rounded to float once
-        const int32_t gap = loc0 > loc1 ? loc0 - loc1 : loc1 - loc0;
-        float rew = (float)(loc0 == loc1 ? 1.0 : -gap * 0.2);
-        if (loc0 < 0 || loc0 >= kSpaces || loc1 < 0 || loc1 >= kSpaces) {
-            over = true;
-            rew = (float)(-kSpaces * (time + 1) * 0.2);
-        }
-        over |= time == 0;
+        float rew;
+        over = move_world(r0, r1, a0, a1, rew);
         if (!over) {  // a finished world's rows come from the reset
             store_row(obs, n, 0, w, r0);
             store_row(obs, n, 1, w, r1);
@@ -237,6 +253,109 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_reset(uint32_t n, uint32_t
     }
 }
 
+// The whole step in ONE launch (mrl_step on one GPU).  A third of the worlds finish in every step (episodes last at most
+// three), so the two-launch pair writes a third of the rows twice over -- stepped rows it then skips, fresh rows as 28-byte
+// pieces scattered by the re-seeding launch -- and that launch costs 15 us of the 36 at 1 M worlds.  Here workgroup b owns
+// worlds [1024 b, 1024 b + 1024), four per thread in registers; a finished world's rows are replaced by the fresh episode's
+// BEFORE they are stored, so every row is written exactly once, in the step's own coalesced stream.  Episode indices come
+// from the single-launch look-back of episode_scan.hpp (a count that does not appear is recounted from that workgroup's rows
+// and actions; rows are stored only behind the __syncthreads that makes the workgroup's own count globally visible).
+constexpr int kFusedWorlds = 4;  // worlds per thread
+__device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *action, const int32_t *obs, uint32_t j, bool sampled, uint64_t seed,
+                                                   uint32_t step)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = j * (kFusedWorlds * kBlock), last = min(n, first + kFusedWorlds * kBlock);
+    uint32_t count = 0;
+    for (uint32_t w0 = first; w0 < last; w0 += 64u) {
+        const uint32_t w = w0 + lane, wc = w < last ? w : first;
+        Row r0 = load_row(obs, n, 0, wc), r1 = load_row(obs, n, 1, wc);
+        int32_t a0, a1;
+        actions_of(action, n, wc, sampled, seed, step, a0, a1);
+        float rew;
+        const bool over = move_world(r0, r1, a0, a1, rew) && w < last;
+        count += (uint32_t)__popcll(__ballot(over));
+    }
+    return count;
+}
+
+__global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, const int32_t *action, int32_t *__restrict__ obs,
+                                                                 float *__restrict__ reward, int32_t *__restrict__ done,
+                                                                 unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
+                                                                 uint32_t *next_counter, uint32_t *__restrict__ reset_count, int32_t *action_out,
+                                                                 uint64_t sample_seed, uint32_t sample_step, const mrl::HealTest heal,
+                                                                 const mrl::DeviceCounter device_counter)
+{
+    __shared__ uint32_t s_wave[kFusedWorlds][kBlock / 64];
+    __shared__ uint32_t s_prefix;
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t first = b * (kFusedWorlds * kBlock), last = min(n, first + kFusedWorlds * kBlock);
+    const bool last_block = b == gridDim.x - 1, sampled = action_out != nullptr;
+    device_counter.apply(episode_base, next_counter, epoch);  // (the launch state may live in device memory: common.hpp)
+    mrl::heal_test_delay(heal, b, gridDim.x, epoch);          // test hook only
+    const uint32_t base = *episode_base;
+    Row r0[kFusedWorlds], r1[kFusedWorlds];
+    float rew[kFusedWorlds];
+    bool over[kFusedWorlds];
+    uint32_t rank[kFusedWorlds];  // among the workgroup's finished worlds, in ascending world order (round u covers worlds first + 256 u ...)
+#pragma unroll
+    for (int u = 0; u < kFusedWorlds; u++) {
+        const uint32_t w = first + u * kBlock + threadIdx.x, wc = w < last ? w : first;
+        r0[u] = load_row(obs, n, 0, wc);
+        r1[u] = load_row(obs, n, 1, wc);
+        int32_t a0, a1;
+        actions_of(action, n, wc, sampled, sample_seed, sample_step, a0, a1);
+        if (sampled && w < last) {
+            action_out[w] = a0;
+            action_out[(size_t)n + w] = a1;
+        }
+        over[u] = move_world(r0[u], r1[u], a0, a1, rew[u]) && w < last;
+        const unsigned long long votes = __ballot(over[u]);
+        rank[u] = (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[u][wave] = (uint32_t)__popcll(votes);
+    }
+    __syncthreads();
+    uint32_t block_total = 0;
+#pragma unroll
+    for (int u = 0; u < kFusedWorlds; u++)
+        for (uint32_t v = 0; v < kBlock / 64; v++) {
+            const uint32_t c = s_wave[u][v];
+            block_total += c;
+#pragma unroll
+            for (int u2 = 0; u2 < kFusedWorlds; u2++)  // everything in front of (round u2, wave `wave`) in world order
+                rank[u2] += (u < u2 || (u == u2 && v < wave)) ? c : 0u;
+        }
+    if (threadIdx.x == 0) mrl::publish_count(status, b, epoch, block_total);
+    __syncthreads();  // the count is globally visible (vmcnt(0) in front of the barrier) before any row of this workgroup changes
+    if (threadIdx.x < 64 && (block_total != 0 || last_block)) {
+        const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
+            return recount_chunk(n, action, obs, j, sampled, sample_seed, sample_step);
+        });
+        if (threadIdx.x == 0) s_prefix = before;
+    }
+    mrl::lds_barrier();
+    const uint32_t before = block_total != 0 || last_block ? s_prefix : 0u;
+    // (Storing the rows of the worlds that go on while the look-back is under way, and the fresh rows behind it, was measured:
+    // 32.6 against 30.4 us per step at 1 M worlds -- the 28-byte rows of neighbouring worlds share cache lines, and writing a
+    // line in two passes costs more than the 2 us of waiting.)
+#pragma unroll
+    for (int u = 0; u < kFusedWorlds; u++) {
+        const uint32_t w = first + u * kBlock + threadIdx.x;
+        if (w < last) {
+            if (over[u]) fresh_rows(base + before + rank[u], r0[u], r1[u]);  // the finished world's next episode, stored in its place
+            store_row(obs, n, 0, w, r0[u]);
+            store_row(obs, n, 1, w, r1[u]);
+            reward[w] = rew[u];
+            reward[(size_t)n + w] = rew[u];
+            done[w] = over[u] ? 1 : 0;
+        }
+    }
+    if (last_block && threadIdx.x == 0) {
+        *reset_count = before + block_total;
+        *next_counter = base + before + block_total;
+    }
+}
+
 __global__ void fill_balance_ids(int32_t *world_id, int32_t *agent_id, int32_t *active, int32_t *mask, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,8 +376,31 @@ struct BalanceSim final : mrl_sim {
     uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     mrl::LaunchStateOwner launch_state;  // parity in device memory once a caller wants to capture steps (common.hpp)
     bool capturable() const override { return launch_state.device_mode; }
-    void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, 0, stream); }
+    void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
+    // single-launch step (mrl_balance_step_fused)
+    unsigned long long *status = nullptr;
+    mrl::HealTest heal;
+    uint32_t fused_grid = 0, epoch = 0;
+    bool fused_step = false;
+
+    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
+    {
+        epoch += 1;
+        if (launch_state.device_mode) launch_state.advance(stream);
+        hipLaunchKernelGGL(mrl_balance_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions ? actions : action, obs, reward,
+                           done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed, sample_step, heal,
+                           launch_state.counter_args(counter));
+        MRL_HIP(hipGetLastError());
+        parity ^= 1u;
+    }
+    void step(const int32_t *actions, hipStream_t stream) override
+    {
+        if (fused_step)
+            launch_fused(actions, nullptr, 0, 0, stream);
+        else
+            mrl_sim::step(actions, stream);
+    }
 
     void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
     {
@@ -291,8 +433,12 @@ struct BalanceSim final : mrl_sim {
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
         for (uint32_t k = 0; k < num_steps; k++) {
-            launch_step(action, action, seed, first_step + k, stream);
-            phase2(nullptr, stream);
+            if (fused_step) {
+                launch_fused(action, action, seed, first_step + k, stream);
+            } else {
+                launch_step(action, action, seed, first_step + k, stream);
+                phase2(nullptr, stream);
+            }
         }
     }
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
@@ -335,7 +481,7 @@ struct BalanceSim final : mrl_sim {
         }
     }
     size_t action_elems() const override { return (size_t)2 * num_worlds; }
-    const char *kernel_name() const override { return "mrl_balance_step"; }
+    const char *kernel_name() const override { return fused_step ? "mrl_balance_step_fused" : "mrl_balance_step"; }
     // actions 8 + both agents' rows r/w 2 * 2 * 28 + reward 8 + done 4
     uint64_t bytes_per_world_step() const override { return 8 + 4 * kRow * 4 + 8 + 4; }
     void launch_shape(uint32_t out[4]) const override
@@ -379,6 +525,16 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         sim->shard_count = sim->arena.alloc<uint32_t>(1);
         sim->launch_state.init(sim->arena);
+        {
+            const uint32_t blocks = (num_worlds + kFusedWorlds * kBlock - 1) / (kFusedWorlds * kBlock);
+            if (blocks <= mrl::kMaxFusedBlocks) {
+                sim->fused_grid = blocks;
+                sim->status = sim->arena.alloc<unsigned long long>(blocks);
+                sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
+                sim->heal.seen = sim->arena.alloc<uint32_t>(blocks);
+                sim->fused_step = mrl::debug_get("fused_step", 0) != 2;  // 0 / 1: one launch (every row written once), 2: the two-launch pair
+            }
+        }
         hipLaunchKernelGGL(fill_balance_ids, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, 0, sim->world_id, sim->agent_id, sim->active,
                            sim->mask, num_worlds);
         MRL_HIP(hipGetLastError());

@@ -137,3 +137,30 @@ def test_steps_captured_in_a_hip_graph_after_prepare(hip_lib):
             assert torch.equal(getattr(eager, name)().to_torch(), getattr(graphed, name)().to_torch()), f"{name} differs after replay {rep}"
     eager.close()
     graphed.close()
+
+
+@pytest.mark.parametrize("n,heal", [(1000, 0), (300001, 0), (300001, 3), (70000, 1), (1 << 20, 0)],
+                         ids=["1000", "300001", "300001_late_workgroups", "70000_all_late", "1M"])
+def test_single_launch_step_equals_two_launches(n, heal, hip_lib):
+    """mrl_step as ONE launch (every row written exactly once: a finished world's rows are replaced by its next episode's before
+    they are stored; episode indices from the self-healing look-back) against the two-launch pair -- also with workgroups
+    made to arrive late, so that higher ones recount them from their rows and actions."""
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    with debug_knobs({"fused_step": 1, "fused_heal_test": heal}):
+        one = make(n)
+    with debug_knobs({"fused_step": 2}):
+        two = make(n)
+    assert one.kernel_name == "mrl_balance_step_fused" and two.kernel_name == "mrl_balance_step"
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    for t in range(25):
+        a = torch.randint(0, 4, (2, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+        one.step_with_actions(a)
+        two.step_with_actions(a)
+        for name in ("observation_tensor", "done_tensor", "reward_tensor", "reset_count_tensor"):
+            assert torch.equal(getattr(one, name)().to_torch(), getattr(two, name)().to_torch()), f"{name} differs at step {t}"
+    one.rollout_random(9, seed=4, first_step=0)
+    two.rollout_random(9, seed=4, first_step=0)
+    assert torch.equal(one.observation_tensor().to_torch(), two.observation_tensor().to_torch())
+    assert torch.equal(one.action_tensor().to_torch(), two.action_tensor().to_torch())
+    one.close()
+    two.close()

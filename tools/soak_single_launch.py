@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from madrona_rl_envs_playground_amd._lib import debug_knobs  # noqa: E402
-from madrona_rl_envs_playground_amd.simulators import CartpoleSimulator, ExecMode, HanabiSimulator  # noqa: E402
+from madrona_rl_envs_playground_amd.simulators import BalanceBeamSimulator, CartpoleSimulator, ExecMode, HanabiSimulator  # noqa: E402
 
 FULL = dict(colors=5, ranks=5, players=2, max_information_tokens=8, max_life_tokens=3)
 
@@ -40,7 +40,7 @@ def run(name, make, extra, getters, steps, chunk, late_every):
                 assert torch.equal(ref, getattr(s, g)().to_torch()), f"{name}: {g} of the {which} differs from the two-launch pair after {done} steps"
         if done % (chunk * late_every) == 0:
             print(f"  {done} steps equal", flush=True)
-    assert all(int(s.scan_timeout_tensor().to_torch().item()) == 0 for s in sims)
+    assert all(int(s.scan_timeout_tensor().to_torch().item()) == 0 for s in sims if hasattr(s, "scan_timeout_tensor"))
     print(f"{name}: {done} steps: single launch == single launch with late workgroups == two launches")
     for s in sims:
         s.close()
@@ -57,6 +57,10 @@ def main():
     for n in (1 << 20, 300001):
         run(f"cartpole {n} worlds", lambda: CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n),
             {"cartpole.no_persistent": 1}, cartpole, steps if n == 1 << 20 else steps // 4, 499, 8)
+    balance = ["observation_tensor", "done_tensor", "reward_tensor", "reset_count_tensor", "action_tensor"]
+    for n in (1 << 20, 300001):
+        run(f"balance beam {n} worlds", lambda: BalanceBeamSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n),
+            {}, balance, steps // 2 if n == 1 << 20 else steps // 4, 499, 8)
 
 
 if __name__ == "__main__":
