@@ -200,6 +200,12 @@ def other_configs(args, torch, local_rank, launches_us):
         sim.rollout_random(1, seed=7, first_step=i)
     us = launches_us(lambda i: sim.rollout_random(1, seed=7, first_step=60 + i), launches)
     h = leg(sim, n, us, f"hanabi {n}", note="one step call per launch duration; uniformly random legal moves drawn by the step kernel")
+    # bytes_per_world_step counts what this engine has to move: the OBSERVATION tensor is a view of the STATE row's first 658
+    # bytes (the reference's state starts with a copy of its observation), so those bytes are written once.  The reference's
+    # own format stores them twice: on THAT byte count the same launch reads as follows
+    ref_bytes = sim.bytes_per_world_step + 658
+    h["reference_format_bytes_per_world_step"] = ref_bytes
+    h["frac_on_reference_format_bytes"] = ref_bytes * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS
     mask, act = sim.action_mask_tensor().to_torch(), sim.action_tensor().to_torch()
 
     def harness(i):

@@ -173,9 +173,13 @@ typedef struct mrl_hanabi_config {
  *   OBSERVATION int8 (2,N,658); ACTION_MASK int32 (2,N,20); REWARD float32 (2,N);
  *   WORLD_ID / AGENT_ID int32 (2,N); STATE int8 (2,N,783);
  *   OBSERVATION, STATE and ACTION_MASK are strided views (see the strides in the
- *   descriptor) into one array of 1536-byte blocks [state 784 | obs 672 | mask 80],
+ *   descriptor) into one array of 896-byte blocks [state 784 | mask 80 | pad 32],
  *   world-major with the two agents of a world back to back: one step writes whole
- *   cache lines only.
+ *   cache lines only.  OBSERVATION is the first 658 bytes of the STATE row -- the same
+ *   memory: the reference fills the state by copying the observation and appending the
+ *   own hand (generateObsState, sim.cpp:367-379), so the two tensors agree on those
+ *   bytes by construction, always (also for the agent whose buffers stay stale: both
+ *   are refreshed together), and this engine writes them once.
  *   GAME uint8 (N, 176): the raw per-world game record (tests only; layout in
  *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last completed step (written by
  *   phase 2); SHARD_COUNT uint32 (1): worlds that finished in the last mrl_step_phase1 -- what the ranks of a

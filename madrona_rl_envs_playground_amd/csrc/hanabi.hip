@@ -17,8 +17,10 @@
 //            moves as a bit mask, with a handful of shifted ORs per section;
 //   phase B  all 64 lanes: expand bits to bytes, 16 bits -> one 16-byte store, so
 //            every row is written with full-width coalesced stores.
-// Everything one agent receives is one 1536-byte block in HBM (state | observation |
-// legal-move mask, see kAgentBlock); the reference-shaped tensors are strided views.
+// Everything one agent receives is one 896-byte block in HBM (state | legal-move mask, see
+// kAgentBlock); the reference-shaped tensors are strided views, and the OBSERVATION tensor is the
+// first 658 bytes of the state row: the reference fills the state by copying the observation
+// (copyObsToState, sim.cpp:333-341), so it holds the same bytes twice.
 //
 // Episode indices come from one global counter in the reference
 // (sim.cpp:449-451).  As for Cartpole the order is fixed to ascending world
@@ -59,18 +61,27 @@ constexpr int kRecordBytes = 176;
 constexpr int kRecordWords = kRecordBytes / 4;
 constexpr int kRecStride = 180;  // LDS stride: 45 words (odd) -> lane-per-record accesses spread over banks
 constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (odd stride)
-// Output rows in HBM: everything one agent of one world receives from a step is ONE 1536-byte
-// block [state 784 | observation 672 | legal-move mask 80], the two agents of a world back to
-// back.  A wave's 32 worlds are 96 KB of contiguous blocks, written with full 1 KB wave stores
-// that cover whole 128-byte lines; the exported tensors are strided views into the blocks.
-// (Separate obs / state / mask arrays with 672 / 784 / 80-byte rows were measured first: every
+// Output rows in HBM: everything one agent of one world receives from a step is ONE 896-byte block
+// [state 784 | legal-move mask 80 | pad 32], the two agents of a world back to back: whole 128-byte
+// lines, written with full-width wave stores; the exported tensors are strided views into the blocks.
+// The OBSERVATION tensor is a view of the state row's first 658 bytes.  The reference builds the
+// state as "a copy of the observation, then the own hand" (generateObsState, sim.cpp:367-379:
+// copyObsToState copies every entry written so far), so observation[i] == state[i] for every i the
+// observation has, always -- also while the ninth information token shifts both, and for the agent
+// whose buffers stay stale: both are refreshed together or not at all.  Writing those 658 bytes once
+// instead of twice takes 42 % off the bytes of a step (rounds 1-2 wrote [state 784 | observation 672 |
+// mask 80] = 1536 bytes per agent).  For configurations whose observation is shorter than 658 entries the
+// view's tail shows own-hand entries of the state where the reference's buffer holds leftovers of its
+// own; the wrappers only ever look at [:obs_size] (envs/hanabi_env.py:92-104).
+// (Separate obs / state / mask arrays with 672 / 784 / 80-byte rows were measured in round 1: every
 // row end shares a line with the next row, the 80-byte mask rows most of all -- dropping the
 // mask stores alone, 5 % of the bytes, took 5 us off a 24 us kernel.)
-constexpr int kObsRow = 672, kStateRow = 784, kMaskRow = 80;
-constexpr int kAgentBlock = kStateRow + kObsRow + kMaskRow;  // 1536
-constexpr int kWorldBlock = 2 * kAgentBlock;                 // 3072
-constexpr int kStateChunks = kStateRow / 16, kObsChunks = kObsRow / 16, kAgentChunks = kAgentBlock / 16;  // 49, 42, 96
+constexpr int kStateRow = 784, kMaskRow = 80, kPadRow = 32;
+constexpr int kAgentBlock = kStateRow + kMaskRow + kPadRow;  // 896
+constexpr int kWorldBlock = 2 * kAgentBlock;                 // 1792
+constexpr int kStateChunks = kStateRow / 16, kMaskChunks = kMaskRow / 16, kAgentChunks = kAgentBlock / 16;  // 49, 5, 56
 static_assert(kAgentBlock % 128 == 0, "agent blocks are whole cache lines");
+static_assert(MRL_HANABI_OBS_SIZE <= MRL_HANABI_STATE_SIZE && MRL_HANABI_STATE_SIZE <= kStateRow, "the observation is a prefix of the state row");
 
 // record layout (bytes); identical to oracle/hanabi_oracle.c's dump
 enum : int {
@@ -91,7 +102,7 @@ struct HanabiParams {
     uint32_t off_flags, off_deck, off_fireworks, off_info, off_life, off_discard, off_last, off_know;
     uint32_t obs_bits, state_bits;
     uint32_t *records;   // N x 44 words
-    uint8_t *rows;       // N x 2 x kAgentBlock (state | obs | mask per agent)
+    uint8_t *rows;       // N x 2 x kAgentBlock (state | mask | pad per agent; the observation is the state row's head)
     int32_t *active;     // 2 x N
     float *reward;       // 2 x N
     int32_t *done;       // N
@@ -897,14 +908,9 @@ __device__ __forceinline__ uint32_t spread4(uint32_t bits)
     return ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
 }
 
-__device__ __forceinline__ uint4 spread16(uint32_t bits)
-{
-    return make_uint4(spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12));
-}
-
-// Phase B: chunk `ch` (16 bytes) of one agent block from that agent's bit vector.  Chunks 0..48
-// are the state row, 49..90 the observation row (the same leading bits, sim.cpp:333-341, cut at
-// the observation's end), 91..95 the legal-move mask as five int32x4.
+// Phase B: chunk `ch` (16 bytes) of one agent block from that agent's bit vector.  Chunks 0..48 are the
+// state row (whose first 658 bytes are the observation), 49..53 the legal-move mask as five int32x4,
+// 54..55 padding up to whole cache lines.
 __device__ __forceinline__ uint32_t clip16(uint32_t raw, uint32_t first, uint32_t limit)
 {
     // bits of [first, first + 16) that lie below `limit`
@@ -912,24 +918,20 @@ __device__ __forceinline__ uint32_t clip16(uint32_t raw, uint32_t first, uint32_
     return room >= 16 ? raw : (room <= 0 ? 0u : raw & ((1u << room) - 1u));
 }
 
+// (component-wise throughout: a select between two uint4 values makes hipcc park them in scratch memory)
 __device__ __forceinline__ uint4 agent_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t ch)
 {
-    const bool is_state = ch < kStateChunks;
-    const uint32_t k = is_state ? ch : ch - kStateChunks;  // 16-bit piece of the bit vector (meaningless for mask chunks)
-    const uint32_t word = enc[min(k >> 1, 24u)];
+    const uint32_t word = enc[min(ch >> 1, 24u)];  // 16-bit piece `ch` of the bit vector (meaningless behind the state row)
     const uint32_t legal = enc[25];
-    // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the
-    // shifted encoding pushes past the row end is dropped (the reference writes it out of bounds)
-    const uint32_t excess = enc[26];
-    const uint32_t limit = is_state ? min(p.state_bits + excess, (uint32_t)MRL_HANABI_STATE_SIZE)
-                                    : min(p.obs_bits + excess, (uint32_t)MRL_HANABI_OBS_SIZE);
-    const uint32_t raw = (word >> ((k & 1u) * 16u)) & 0xFFFFu;
-    uint4 v = spread16(clip16(raw, k * 16u, limit));
-    if (ch >= kStateChunks + kObsChunks) {
-        const uint32_t bits = legal >> (4u * (ch - (kStateChunks + kObsChunks)));
-        v = make_uint4(bits & 1u, (bits >> 1) & 1u, (bits >> 2) & 1u, (bits >> 3) & 1u);
-    }
-    return v;
+    // the row is MRL_HANABI_STATE_SIZE wide whatever the configuration; what the shifted encoding pushes past
+    // its end is dropped (the reference writes it out of bounds)
+    const uint32_t limit = min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE);
+    const uint32_t piece = clip16((word >> ((ch & 1u) * 16u)) & 0xFFFFu, ch * 16u, limit);
+    const bool is_state = ch < (uint32_t)kStateChunks;
+    const uint32_t m = ch - kStateChunks;  // mask chunk 0..4, padding behind
+    const uint32_t bits = (!is_state && m < (uint32_t)kMaskChunks) ? legal >> (4u * m) : 0u;
+    return make_uint4(is_state ? spread4(piece) : (bits & 1u), is_state ? spread4(piece >> 4) : ((bits >> 1) & 1u),
+                      is_state ? spread4(piece >> 8) : ((bits >> 2) & 1u), is_state ? spread4(piece >> 12) : ((bits >> 3) & 1u));
 }
 
 struct WaveLds {
@@ -945,59 +947,21 @@ __device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
     return WaveLds{base, reinterpret_cast<uint32_t *>(base + kWorldsPerWave * kRecStride)};
 }
 
-// Phase B for a wave's movers: the 96 chunks of an agent block times the wave's worlds, 64 chunks per
-// store.  Three stores cover exactly two worlds, so which chunk (state / observation / mask piece, bit
-// range, word of the bit vector) a lane writes in each of the three is fixed for the whole launch and is
-// worked out once; the loop only adds the pair's LDS base, clips, spreads and stores.
+// Phase B for a wave's movers: the 56 chunks of an agent block times the wave's worlds, 64 chunks per store -- 28 full-width
+// stores for 32 worlds.  Chunk f of that run belongs to world f / 56 (a multiply-shift) and is chunk f % 56 of its block.
 __device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveLds &l, uint32_t nw, unsigned long long overs,
                                               unsigned long long movers, __amdgpu_buffer_rsrc_t out, uint32_t lane)
 {
-    uint32_t wsel[3], ch16[3], woff[3], sh[3], first[3], base_bits[3], cap[3], mshift[3];
-    bool is_mask[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const uint32_t f = (uint32_t)t * kWave + lane;                       // 0..191 within the pair
-        wsel[t] = f >= (uint32_t)kAgentChunks ? 1u : 0u;
-        const uint32_t ch = f - wsel[t] * kAgentChunks;
-        const bool is_state = ch < (uint32_t)kStateChunks;
-        is_mask[t] = ch >= (uint32_t)(kStateChunks + kObsChunks);
-        const uint32_t k = is_state ? ch : ch - kStateChunks;
-        ch16[t] = ch * 16u;
-        woff[t] = wsel[t] * (2u * kEncWords) + min(k >> 1, 24u);            // word of the pair's bit vectors
-        sh[t] = (k & 1u) * 16u;
-        first[t] = k * 16u;
-        base_bits[t] = is_state ? p.state_bits : p.obs_bits;
-        cap[t] = is_state ? (uint32_t)MRL_HANABI_STATE_SIZE : (uint32_t)MRL_HANABI_OBS_SIZE;
-        mshift[t] = is_mask[t] ? 4u * (ch - (kStateChunks + kObsChunks)) : 0u;
-    }
-    for (uint32_t r0 = 0; r0 < nw; r0 += 2) {
-        const uint32_t *pair = l.enc + r0 * 2 * kEncWords;
-        const uint32_t mv0 = (uint32_t)(movers >> r0) & 1u, mv1 = (uint32_t)(movers >> (r0 + 1u)) & 1u;
-        const bool skip0 = (overs >> r0) & 1ull, skip1 = ((overs >> (r0 + 1u)) & 1ull) || r0 + 1u >= nw;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t *mine = pair + wsel[t] * (2u * kEncWords);
-            const uint32_t word = pair[woff[t]];
-            const uint32_t legal = mine[25], excess = mine[26];
-            // rows are MRL_HANABI_OBS_SIZE / _STATE_SIZE wide whatever the configuration; what the shifted
-            // encoding pushes past the row end is dropped (the reference writes it out of bounds)
-            const uint32_t limit = min(base_bits[t] + excess, cap[t]);
-            // (component-wise: a select between two uint4 values makes hipcc park them in scratch memory)
-            const uint32_t piece = clip16((word >> sh[t]) & 0xFFFFu, first[t], limit);
-            uint32_t v0 = spread4(piece), v1 = spread4(piece >> 4), v2 = spread4(piece >> 8), v3 = spread4(piece >> 12);
-            if (t > 0) {  // the first store of a pair holds no mask chunk
-                const uint32_t bits = legal >> mshift[t];
-                v0 = is_mask[t] ? (bits & 1u) : v0;
-                v1 = is_mask[t] ? ((bits >> 1) & 1u) : v1;
-                v2 = is_mask[t] ? ((bits >> 2) & 1u) : v2;
-                v3 = is_mask[t] ? ((bits >> 3) & 1u) : v3;
-            }
-            const uint4 v = make_uint4(v0, v1, v2, v3);
-            const uint32_t agent = wsel[t] ? mv1 : mv0;
-            const bool skip = wsel[t] ? skip1 : skip0;
-            const uint32_t at = skip ? 0xFFFFFFF0u : (r0 + wsel[t]) * kWorldBlock + agent * kAgentBlock + ch16[t];  // out of range = dropped
-            row_store(out, at, v);
-        }
+    const uint32_t total = nw * kAgentChunks;  // <= 1792
+#pragma unroll 2
+    for (uint32_t f = lane; f < total + lane; f += kWave) {  // uniform trip count; lanes behind the run store nothing
+        const uint32_t r = (f * 2341u) >> 17;  // f / 56, exact for f < 4096
+        const uint32_t ch = f - r * kAgentChunks;
+        const uint4 v = agent_chunk(p, l.enc + r * 2 * kEncWords, ch);  // (r <= 31: inside the wave's LDS whatever nw is)
+        const uint32_t agent = (uint32_t)(movers >> r) & 1u;
+        const bool skip = f >= total || ((overs >> r) & 1ull);  // a finished world's rows come from the re-deal
+        const uint32_t at = skip ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;  // out of range = dropped by the descriptor
+        row_store(out, at, v);
     }
 }
 
@@ -1225,7 +1189,7 @@ __device__ __forceinline__ void reset_body(const HanabiParams &p, uint8_t *smem,
             const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)world);
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)ws * kWorldBlock, kWorldBlock);
 #pragma unroll
-            for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {  // both agents: 3 full wave stores
+            for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {  // both agents: 112 chunks
                 const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
                 row_store(out, f * 16u, agent_chunk(p, l.enc + (r * 2 + agent) * kEncWords, f - agent * kAgentChunks));
             }
@@ -1848,10 +1812,11 @@ struct HanabiSim final : mrl_sim {
         case MRL_HANABI_ACTIVE_AGENT: *out = mrl::make_desc(params.active, MRL_INT32, device, {2, N}); return true;
         case MRL_HANABI_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {2, N, 1}); return true;
         case MRL_HANABI_OBSERVATION:
-            *out = mrl::make_desc(params.rows + kStateRow, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {kAgentBlock, kWorldBlock, 1});
+            // the head of the state row: the reference fills the state by copying the observation (see kAgentBlock)
+            *out = mrl::make_desc(params.rows, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {kAgentBlock, kWorldBlock, 1});
             return true;
         case MRL_HANABI_ACTION_MASK:
-            *out = mrl::make_desc(params.rows + kStateRow + kObsRow, MRL_INT32, device, {2, N, 20}, {kAgentBlock / 4, kWorldBlock / 4, 1});
+            *out = mrl::make_desc(params.rows + kStateRow, MRL_INT32, device, {2, N, 20}, {kAgentBlock / 4, kWorldBlock / 4, 1});
             return true;
         case MRL_HANABI_REWARD: *out = mrl::make_desc(params.reward, MRL_FLOAT32, device, {2, N}); return true;
         case MRL_HANABI_WORLD_ID: *out = mrl::make_desc(world_id, MRL_INT32, device, {2, N}); return true;
@@ -1878,9 +1843,10 @@ struct HanabiSim final : mrl_sim {
 
     uint64_t bytes_per_world_step() const override
     {
-        // action 8 + record r/w 2*176 + obs 658 + state 783 + mask 80 +
-        // active 8 + reward 8 + done 4 (non-reset step: one agent re-encoded)
-        return 8 + 2 * kRecordBytes + 658 + 783 + 80 + 8 + 8 + 4;
+        // SURVEY.md section 8d's list with this engine's sizes: action 8 + record r/w 2*176 + state 783 (its head IS the
+        // observation: the reference's second copy of those 658 bytes is a view here) + mask 80 + active 8 + reward 8 +
+        // done 4 (non-reset step: one agent re-encoded)
+        return 8 + 2 * kRecordBytes + 783 + 80 + 8 + 8 + 4;
     }
 };
 

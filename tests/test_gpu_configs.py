@@ -196,7 +196,7 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
     for name, leg in legs.items():
         assert leg["launches_timed"] >= 300 and leg["kernel_us_avg"] > 0 and leg["value"] > 0 and leg["kernel"].startswith("mrl_"), name
         assert abs(leg["frac"] - leg["bytes_per_world_step"] * leg["worlds"] / (leg["kernel_us_avg"] * 1e-6) / 8e12) < 1e-9
-    assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 1901
+    assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 1243
     assert legs["hanabi_65536"]["harness_loop_us_per_step"] > legs["hanabi_65536"]["kernel_us_avg"]
     # traffic: only ever from this build's PMC passes
     try:
