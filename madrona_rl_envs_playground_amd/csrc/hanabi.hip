@@ -1277,6 +1277,53 @@ __device__ __forceinline__ uint32_t recount_chunk(const HanabiParams &p, uint8_t
     return count;
 }
 
+// The scan wave's re-deal: the workgroup's finished worlds dealt anew IN their slots of the stepping waves' LDS (record and
+// both agents' bit vectors), 32 per round, in ascending world order: entry e is the (first_episode + e)-th episode
+// (entries of wave w: start_of[w] .. start_of[w + 1]; s_fin[w][i] = the wave's i-th finished world).  Their rows are
+// written by the wave that owns the slot, at the end of its own stream of stores: from the scan wave every store would be
+// a round trip of its own through a saturated fabric (measured: 14 us for five worlds).
+template <int kV>
+__device__ __forceinline__ void deal_finished_worlds(const HanabiParams &p, uint8_t *smem, const uint8_t (*s_fin)[kWorldsPerWave],
+                                                     const uint32_t (&start_of)[kWavesPerBlock + 1], uint32_t first_episode, uint32_t lane)
+{
+    constexpr int kR = kV ? 5 : 0;
+    const uint32_t block_total = start_of[kWavesPerBlock];
+    for (uint32_t e0 = 0; e0 < block_total; e0 += kWorldsPerWave) {
+        const uint32_t here = min((uint32_t)kWorldsPerWave, block_total - e0);
+        uint32_t wv = 0, local = 0;  // entry e0 + (lane & 31): which wave's slot
+        {
+            const uint32_t e = e0 + (lane & 31u);
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; w++) wv += e >= start_of[w] ? 1u : 0u;
+            uint32_t first = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) first = wv == (uint32_t)w ? start_of[w] : first;
+            local = (lane & 31u) < here ? s_fin[wv][e - first] : 0u;
+        }
+        const WaveLds slot = wave_lds(smem, wv);
+        uint8_t *rec = slot.rec + local * kRecStride;
+        if (lane < here) deal_new_game<kR>(p, rec, first_episode + e0 + lane);
+        wave_lds_sync();
+        // the two agents of a fresh game side by side: lanes 0..31 agent 0, lanes 32..63 agent 1
+        if ((lane & 31u) < here) encode_fresh<kV>(p, rec, slot.enc + (local * 2 + (lane >> 5)) * kEncWords, lane >> 5);
+        wave_lds_sync();
+    }
+}
+
+// The rows of a stepping wave's finished worlds (both agents' blocks of each), from the bit vectors the scan wave left in LDS
+__device__ __forceinline__ void store_fresh_rows(const HanabiParams &p, const WaveLds &l, const uint8_t *fin, uint32_t mine, uint32_t w0, uint32_t lane)
+{
+    for (uint32_t j = 0; j < mine; j++) {
+        const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane((int)fin[j]);
+        const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)(w0 + who) * kWorldBlock, kWorldBlock);
+#pragma unroll
+        for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {
+            const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
+            row_store(out, f * 16u, agent_chunk(p, l.enc + (who * 2 + agent) * kEncWords, f - agent * kAgentChunks));
+        }
+    }
+}
+
 // The whole step in ONE launch (mrl_step on one GPU, batches of one sub-block per workgroup: up to 262144 worlds):
 // transition, look-back over the lower workgroups' finished counts instead of a kernel boundary, re-deal.  Workgroup
 // b owns worlds [256 b, 256 b + 256) and has NINE waves: eight step 32 worlds each exactly like mrl_hanabi_step
@@ -1301,7 +1348,6 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
                       unsigned long long *status, uint32_t epoch, const uint32_t *episode_base, uint32_t *next_counter,
                       uint32_t *reset_count, uint32_t *heal_seen, const mrl::DeviceCounter device_counter)
 {
-    constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ __attribute__((aligned(16))) uint8_t s_scratch[kWorldsPerWave * kRecStride];  // the scan wave's copy of another workgroup's records (healing)
     __shared__ uint32_t s_counts[kWavesPerBlock];
@@ -1355,36 +1401,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             *reset_count = before + block_total;
             *next_counter = base + before + block_total;
         }
-        // Deal the workgroup's finished worlds anew IN their slots of the stepping waves' LDS (record and both agents'
-        // bit vectors), 32 per round, in ascending world order: entry e is the (before + e)-th finished world of the
-        // step (entries of wave w: start_of[w] .. start_of[w + 1]).  Their rows and records are written by the wave
-        // that owns the slot, at the end of its own stream of stores: from here every store would be a round trip of
-        // its own through a saturated fabric (measured: 14 us for five worlds).
-        for (uint32_t e0 = 0; e0 < block_total; e0 += kWorldsPerWave) {
-            const uint32_t here = min((uint32_t)kWorldsPerWave, block_total - e0);
-            uint32_t wv = 0, local = 0;  // entry e0 + (lane & 31): which wave's slot
-            {
-                const uint32_t e = e0 + (lane & 31u);
-#pragma unroll
-                for (int w = 1; w < kWavesPerBlock; w++) wv += e >= start_of[w] ? 1u : 0u;
-                uint32_t first = 0;
-#pragma unroll
-                for (int w = 0; w < kWavesPerBlock; w++) first = wv == (uint32_t)w ? start_of[w] : first;
-                local = (lane & 31u) < here ? s_fin[wv][e - first] : 0u;
-            }
-            const WaveLds slot = wave_lds(smem, wv);
-            uint8_t *rec = slot.rec + local * kRecStride;
-            const uint32_t world = bid * kWorldsPerBlock + wv * kWorldsPerWave + local;
-            if (lane < here) {
-                deal_new_game<kR>(p, rec, base + before + e0 + lane);
-                p.active[world] = 1;
-                p.active[(size_t)N + world] = 0;
-            }
-            wave_lds_sync();
-            // the two agents of a fresh game side by side: lanes 0..31 agent 0, lanes 32..63 agent 1
-            if ((lane & 31u) < here) encode_fresh<kV>(p, rec, slot.enc + (local * 2 + (lane >> 5)) * kEncWords, lane >> 5);
-            wave_lds_sync();
-        }
+        deal_finished_worlds<kV>(p, smem, s_fin, start_of, base + before, lane);
         if (lane == 0) __hip_atomic_store(&s_ready, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FSTAMP_SCAN(2);
         return;
@@ -1425,11 +1442,14 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             const uint32_t next = rec[R_CUR] & 1u;
             next_is_1 = next != 0;
             encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
-            p.active[(size_t)next * N + world] = 1;
-            p.active[(size_t)(next ^ 1u) * N + world] = 0;
+            over = m.over;
+            // (a finished world's next episode opens with agent 0 to move, sim.cpp:446-532: written here, so that every
+            // ACTIVE word has one writer -- two waves' stores to one address are ordered by nothing short of a wait for the first)
+            const uint32_t mover = over ? 0u : next;
+            p.active[(size_t)mover * N + world] = 1;
+            p.active[(size_t)(mover ^ 1u) * N + world] = 0;
             p.reward[world] = m.reward;
             p.reward[(size_t)N + world] = m.reward;
-            over = m.over;
             p.done[world] = over ? 1 : 0;
         }
         const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
@@ -1459,15 +1479,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     const uint32_t need = mine != 0 ? 2u : 1u;
     while (__hip_atomic_load(&s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
-    for (uint32_t j = 0; j < mine; j++) {
-        const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fin[wib][j]);
-        const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)(w0 + who) * kWorldBlock, kWorldBlock);
-#pragma unroll
-        for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {
-            const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
-            row_store(out, f * 16u, agent_chunk(p, l.enc + (who * 2 + agent) * kEncWords, f - agent * kAgentChunks));
-        }
-    }
+    store_fresh_rows(p, l, s_fin[wib], mine, w0, lane);
     store_records(p, l, w0, nw, lane);
     FSTAMP(6);
 }
@@ -1477,7 +1489,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
 // masked-random policy with the game records resident in LDS.  Every step still writes the
 // mover's rows, rewards, dones and the ACTION tensor, and episodes are numbered exactly as by
 // the one-launch-per-step path, which takes two grid-wide hand-offs per step:
-//   * finished counts of the LOWER workgroups in this step (waited for, as in the single step);
+//   * finished counts of the LOWER workgroups in this step (waited for);
 //   * finished counts of ALL workgroups in the previous step (published a whole step earlier),
 //     so that every workgroup knows the step's first episode index without a counter in HBM.
 // Counts travel through a ring of four status arrays tagged with the step's epoch; a workgroup
@@ -1486,80 +1498,51 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
 // kernel NEEDS all its workgroups resident at once (nobody exits before the last step): the host
 // launches it cooperatively (the runtime refuses a grid the device cannot hold at once) and falls
 // back to one launch per step when that fails.  Waits are bounded as everywhere (SCAN_TIMEOUT).
+//
+// The workgroup is the single step's: four leader waves run phase A for 64 worlds each, all eight
+// stepping waves stream out their 32 worlds' rows, and the ninth -- the scan wave -- does both
+// hand-offs and deals the finished worlds anew in LDS meanwhile, so that neither the look-back nor
+// the ten dependent draws of a new game are in a stepping wave's instruction stream (with the
+// re-deal in the stepping waves a step took 20.3 us, as long as a launch per step).  A step ends
+// with a barrier: the next phase A rewrites the bit vectors phase B reads.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 4;
 
 template <int kV>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRL_HANABI_EU)))
-mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoch0, uint32_t num_steps, uint32_t first_step,
+__global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_eu(3)))
+mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epoch0, uint32_t num_steps, uint32_t first_step,
                    const uint32_t *episode_base, uint32_t *next_counter, uint32_t *reset_count, const mrl::Alarm timed_out)
 {
-    constexpr int kR = kV ? 5 : 0;
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
-    __shared__ uint32_t s_counts2[2][kWavesPerBlock];  // double-buffered by step parity: no barrier at the end of a step
-    __shared__ uint32_t s_part2[2][2];
+    __shared__ uint32_t s_counts[kWavesPerBlock];
+    __shared__ uint32_t s_dealt;  // the number of steps whose fresh games are in LDS
     __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
+    __shared__ uint32_t s_overs[kWavesPerBlock], s_movers[kWavesPerBlock];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const WaveLds l = wave_lds(smem, wib);
+    const bool scan_wave = wib == (uint32_t)kWavesPerBlock;
+    HanabiParams p = p0;
     const uint32_t N = p.num_worlds, G = gridDim.x, b = blockIdx.x;
     const uint32_t w0 = b * kWorldsPerBlock + wib * kWorldsPerWave;
-    const uint32_t nw = w0 < N ? min((uint32_t)kWorldsPerWave, N - w0) : 0u;
-    const bool last_block = b == G - 1;
-    uint32_t base = *episode_base;  // first episode index of the current step
-    uint32_t last_total = 0;
-
+    const uint32_t nw = (!scan_wave && w0 < N) ? min((uint32_t)kWorldsPerWave, N - w0) : 0u;
+    const WaveLds l = wave_lds(smem, scan_wave ? 0u : wib);
+    if (threadIdx.x == 0) s_dealt = 0u;
     load_records(p, l, w0, nw, lane);
-    wave_lds_sync();
+    mrl::lds_barrier();  // every wave's records are in LDS (a leader steps its partner's worlds too)
 
-    for (uint32_t k = 0; k < num_steps; k++) {
-        const uint32_t epoch = epoch0 + k;
-        uint32_t *s_counts = s_counts2[k & 1u], *s_part = s_part2[k & 1u];
-        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
-        const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
-
-        // ---- phase A: draw, act, encode the next mover ----
-        bool over = false, next_is_1 = false;
-        if (lane < nw) {
-            uint8_t *rec = l.rec + lane * kRecStride;
-            const uint32_t world = w0 + lane;
-            const uint32_t actor = rec[R_CUR] & 1u;
-            const uint32_t legal = legal_moves<kR>(p, rec, actor);
-            const uint32_t count = (uint32_t)__popc(legal);
-            const uint32_t uid =
-                count ? mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, first_step + k, world, actor), count)) : 0u;
-            p.action_out[(size_t)actor * N + world] = (int32_t)uid;
-            apply_variant<kV>(p, rec, uid);
-            const uint32_t next = rec[R_CUR] & 1u;
-            next_is_1 = next != 0;
-            encode_variant<kV>(p, rec, l.enc + lane * 2 * kEncWords, next);
-            p.active[(size_t)next * N + world] = 1;
-            p.active[(size_t)(next ^ 1u) * N + world] = 0;
-            const int32_t old_score = (int8_t)rec[R_SCORE];
-            int32_t score = 0;
-            if (rec[R_LIFE] > 0)
-                for (uint32_t c = 0; c < p.colors; c++) score += rec[R_FIREWORKS + c];
-            rec[R_SCORE] = (uint8_t)score;
-            rec[R_NEWREW] = (uint8_t)(score - old_score);
-            const float rew = (float)(int8_t)(score - old_score);
-            p.reward[world] = rew;
-            p.reward[(size_t)N + world] = rew;
-            over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
-            p.done[world] = over ? 1 : 0;
-        }
-        const unsigned long long overs = __ballot(over);
-        const unsigned long long movers = __ballot(next_is_1);
-        const uint32_t mine = (uint32_t)__popcll(overs);
-        if (over) s_fin[wib][__popcll(overs & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-        if (lane == 0) s_counts[wib] = mine;
-        mrl::lds_barrier();
-        uint32_t in_block_before = 0, block_total = 0;
-        for (uint32_t w = 0; w < kWavesPerBlock; w++) {
-            in_block_before += w < wib ? s_counts[w] : 0u;
-            block_total += s_counts[w];
-        }
-        // ---- the grid-wide hand-offs, by the last wave, before its own row stores ----
-        if (wib == kWavesPerBlock - 1) {
+    if (scan_wave) {
+        // ================= the scan wave =================
+        uint32_t base = *episode_base;  // first episode index of the current step
+        for (uint32_t k = 0; k < num_steps; k++) {
+            const uint32_t epoch = epoch0 + k;
+            unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+            const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
+            mrl::lds_barrier();  // phase A is through: s_counts and s_fin are there
+            uint32_t start_of[kWavesPerBlock + 1];
+            start_of[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) start_of[w + 1] = start_of[w] + s_counts[w];
+            const uint32_t block_total = start_of[kWavesPerBlock];
             if (lane == 0) mrl::publish_count(now, b, epoch, block_total);
             uint32_t lower = 0, prev_all = 0, unused = 0;
             if (k > 0)  // everybody's count of the previous step (published long ago)
@@ -1571,65 +1554,78 @@ mrl_hanabi_rollout(const HanabiParams p, unsigned long long *ring, uint32_t epoc
                 lower += __shfl_xor(lower, off, 64);
                 prev_all += __shfl_xor(prev_all, off, 64);
             }
+            base += prev_all;  // previous step's finished worlds, all workgroups (0 in the first step)
+            deal_finished_worlds<kV>(p, smem, s_fin, start_of, base + lower, lane);
+            if (lane == 0) __hip_atomic_store(&s_dealt, k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            mrl::lds_barrier();  // the step's end
+        }
+        // the counter after the rollout: the last step's counts of everybody (the last workgroup has the
+        // highest index, so these are "lower" counts plus its own and the usual wait applies)
+        if (b == G - 1 && num_steps > 0) {
+            const uint32_t epoch = epoch0 + num_steps - 1u;
+            const unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
+            uint32_t all = 0, unused = 0;
+            for (uint32_t first = 0; first < G; first += kWave * 8u) all += mrl::read_counts<8>(now, first, G, epoch, 0u, &unused, timed_out);
+            for (int off = 32; off > 0; off >>= 1) all += __shfl_xor(all, off, 64);
             if (lane == 0) {
-                s_part[0] = lower;
-                s_part[1] = prev_all;
+                *reset_count = all;
+                *next_counter = base + all;
             }
         }
+        return;
+    }
 
-        // ---- phase B: the movers' rows of the worlds that go on ----
-        {
-            const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
-            expand_movers(p, l, nw, overs, movers, out, lane);
+    // ================= the eight stepping waves =================
+    const bool leader = wib < 4;                        // waves w and w + 4 share a SIMD (mrl_hanabi_step_fused)
+    const uint32_t half = lane >> 5, idx = lane & 31u;
+    const uint32_t slot = wib + half * 4u;              // whose worlds this lane steps in phase A
+    const uint32_t a_w0 = b * kWorldsPerBlock + slot * kWorldsPerWave;
+    const uint32_t a_nw = (leader && a_w0 < N) ? min((uint32_t)kWorldsPerWave, N - a_w0) : 0u;
+    const WaveLds ls = wave_lds(smem, leader ? slot : wib);
+    const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
+    for (uint32_t k = 0; k < num_steps; k++) {
+        // ---- phase A: draw, act, encode the next mover ----
+        if (leader) {
+            p.sample_step = first_step + k;
+            bool over = false, next_is_1 = false;
+            if (idx < a_nw) {
+                uint8_t *rec = ls.rec + idx * kRecStride;
+                const uint32_t world = a_w0 + idx;
+                const Moved m = move_world<kV>(p, rec, world, 0, 0, true);
+                const uint32_t next = rec[R_CUR] & 1u;
+                next_is_1 = next != 0;
+                encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                over = m.over;
+                const uint32_t mover = over ? 0u : next;  // (a new game opens with agent 0: one writer per ACTIVE word)
+                p.active[(size_t)mover * N + world] = 1;
+                p.active[(size_t)(mover ^ 1u) * N + world] = 0;
+                p.reward[world] = m.reward;
+                p.reward[(size_t)N + world] = m.reward;
+                p.done[world] = over ? 1 : 0;
+            }
+            const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
+            const uint32_t my_overs = (uint32_t)(half ? all_overs >> 32 : all_overs), my_movers = (uint32_t)(half ? all_movers >> 32 : all_movers);
+            if (over) s_fin[slot][__popc(my_overs & ((1u << idx) - 1u))] = (uint8_t)idx;
+            if (idx == 0) {
+                s_counts[slot] = (uint32_t)__popc(my_overs);
+                s_overs[slot] = my_overs;
+                s_movers[slot] = my_movers;
+            }
         }
-        mrl::lds_barrier();  // s_part is there; s_counts / s_fin have been read by everybody
-        const uint32_t lower = s_part[0];
-        base += s_part[1];  // previous step's finished worlds, all workgroups (0 in the first step)
-        last_total = s_part[1];
+        mrl::lds_barrier();  // hands the finished worlds to the scan wave (and a partner's ballots back to it)
+        const unsigned long long overs = s_overs[wib], movers = s_movers[wib];
+        const uint32_t mine = (uint32_t)__popcll(overs);
 
-        // ---- re-deal this wave's finished worlds in place ----
+        // ---- phase B: the movers' rows of the worlds that go on; then the finished worlds' new rows ----
+        expand_movers(p, l, nw, overs, movers, out, lane);
         if (mine != 0) {
-            if (over) {
-                const uint32_t rank = (uint32_t)__popcll(overs & ((1ull << lane) - 1ull));
-                deal_new_game<kR>(p, l.rec + lane * kRecStride, base + lower + in_block_before + rank);
-                p.active[w0 + lane] = 1;
-                p.active[(size_t)N + w0 + lane] = 0;
-            }
-            wave_lds_sync();
-            if (lane < 2 * mine) {
-                const uint32_t who = s_fin[wib][lane >> 1];
-                encode_fresh<kV>(p, l.rec + who * kRecStride, l.enc + (who * 2 + (lane & 1u)) * kEncWords, lane & 1u);
-            }
-            wave_lds_sync();
-            for (uint32_t j = 0; j < mine; j++) {
-                const uint32_t who = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_fin[wib][j]);
-                const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)(w0 + who) * kWorldBlock, kWorldBlock);
-#pragma unroll
-                for (uint32_t f = lane; f < 2 * kAgentChunks; f += kWave) {
-                    const uint32_t agent = f >= kAgentChunks ? 1u : 0u;
-                    row_store(out, f * 16u, agent_chunk(p, l.enc + (who * 2 + agent) * kEncWords, f - agent * kAgentChunks));
-                }
-            }
+            while (__hip_atomic_load(&s_dealt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            store_fresh_rows(p, l, s_fin[wib], mine, w0, lane);
         }
-        // (no barrier here: the next step uses the other halves of s_counts2 / s_part2, and nobody can be two
-        // steps ahead of a wave that has not passed this step's second barrier)
+        mrl::lds_barrier();  // the step's end: the next phase A rewrites what phase B and the scan wave have read
     }
-
     store_records(p, l, w0, nw, lane);
-    // the counter after the rollout: the last step's counts of everybody (the last workgroup has the
-    // highest index, so these are "lower" counts plus its own and the usual wait applies)
-    if (last_block && wib == kWavesPerBlock - 1 && num_steps > 0) {
-        const uint32_t epoch = epoch0 + num_steps - 1u;
-        unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
-        uint32_t all = 0, unused = 0;
-        for (uint32_t first = 0; first < G; first += kWave * 8u) all += mrl::read_counts<8>(now, first, G, epoch, 0u, &unused, timed_out);
-        for (int off = 32; off > 0; off >>= 1) all += __shfl_xor(all, off, 64);
-        if (lane == 0) {
-            *reset_count = all;
-            *next_counter = base + all;
-        }
-    }
-    (void)last_total;
 }
 
 __global__ void fill_agent_ids(int32_t *world_id, int32_t *agent_id, uint32_t n)
@@ -1698,7 +1694,7 @@ struct HanabiSim final : mrl_sim {
         uint32_t *next = counter + (parity ^ 1u);
         mrl::Alarm al = alarm.alarm();
         void *args[] = {&a, &ring, &epoch0, &num_steps, &first_step, &base, &next, &reset_count, &al};
-        const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_hanabi_rollout<kV>), dim3(grid), dim3(kBlock),
+        const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_hanabi_rollout<kV>), dim3(grid), dim3(kFusedBlock),
                                                           args, 0, stream);
         if (err != hipSuccess) {
             (void)hipGetLastError();
@@ -1958,7 +1954,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
             const void *fn = sim->variant == 2 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<2>)
                              : sim->variant == 1 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<1>)
                                                  : reinterpret_cast<const void *>(&mrl_hanabi_rollout<0>);
-            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, 0));
+            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFusedBlock, 0));
             MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
             // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
             // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)
