@@ -219,6 +219,7 @@ def other_configs(args, torch, local_rank, launches_us):
                           max_information_tokens=8, max_life_tokens=3)
     sim.rollout_random(50, seed=7, first_step=0)
     h["persistent_rollout_us_per_step"] = launches_us(lambda i: sim.rollout_random(300, seed=7, first_step=50 + 300 * i), 2) / 300
+    h["rollout_kernel"] = sim.rollout_kernel_name  # (the step kernel's name here = the runtime refused the cooperative launch)
     sim.close()
     out[f"hanabi_{n}"] = h
     return out

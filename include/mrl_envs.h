@@ -404,6 +404,11 @@ int mrl_game(const mrl_sim *sim);
 uint32_t mrl_num_worlds(const mrl_sim *sim);
 /* name of the dominant kernel of this simulator's step, as rocprofv3 prints it */
 const char *mrl_kernel_name(const mrl_sim *sim);
+/* name of the kernel the next mrl_rollout_random will run: a persistent one ("mrl_hanabi_rollout", "mrl_cartpole_rollout":
+ * all steps in one cooperative launch) while the device can hold the whole grid at once, otherwise mrl_kernel_name's, once per
+ * step.  A cooperative launch the runtime refuses switches the simulator to the latter for good; tests and benchmarks read
+ * this to know which of the two they are looking at. */
+const char *mrl_rollout_kernel_name(const mrl_sim *sim);
 /* algorithmic HBM bytes one step moves per world */
 uint64_t mrl_bytes_per_world_step(const mrl_sim *sim);
 void mrl_destroy(mrl_sim *sim);

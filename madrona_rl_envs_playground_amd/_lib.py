@@ -27,7 +27,7 @@ MAX_DIMS = 6
 SYMBOLS = [
     "mrl_overcooked_create", "mrl_hanabi_create", "mrl_cartpole_create", "mrl_step", "mrl_step_with_actions",
     "mrl_step_phase1", "mrl_step_phase2", "mrl_set_episode_counter", "mrl_reseed_shard", "mrl_tensor", "mrl_game",
-    "mrl_num_worlds", "mrl_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
+    "mrl_num_worlds", "mrl_kernel_name", "mrl_rollout_kernel_name", "mrl_bytes_per_world_step", "mrl_destroy", "mrl_last_error",
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
     "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
     "mrl_step_phase2_gathered", "mrl_set_observation_output", "mrl_set_observation_ring", "mrl_prepare_graph_capture", "mrl_step_many",
@@ -125,6 +125,8 @@ def lib():
     L.mrl_num_worlds.restype = u32
     L.mrl_kernel_name.argtypes = [vp]
     L.mrl_kernel_name.restype = ctypes.c_char_p
+    L.mrl_rollout_kernel_name.argtypes = [vp]
+    L.mrl_rollout_kernel_name.restype = ctypes.c_char_p
     L.mrl_bytes_per_world_step.argtypes = [vp]
     L.mrl_bytes_per_world_step.restype = ctypes.c_uint64
     L.mrl_destroy.argtypes = [vp]

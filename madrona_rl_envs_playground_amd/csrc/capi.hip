@@ -393,6 +393,7 @@ int mrl_tensor(mrl_sim *sim, int slot, mrl_tensor_desc *out)
 int mrl_game(const mrl_sim *sim) { return sim ? sim->game : 0; }
 uint32_t mrl_num_worlds(const mrl_sim *sim) { return sim ? sim->num_worlds : 0; }
 const char *mrl_kernel_name(const mrl_sim *sim) { return sim ? sim->kernel_name() : ""; }
+const char *mrl_rollout_kernel_name(const mrl_sim *sim) { return sim ? sim->rollout_kernel_name() : ""; }
 uint64_t mrl_bytes_per_world_step(const mrl_sim *sim) { return sim ? sim->bytes_per_world_step() : 0; }
 
 void mrl_destroy(mrl_sim *sim)

@@ -488,7 +488,7 @@ struct CartpoleSim final : mrl_sim {
     void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     bool scan_timed_out() const override { return alarm.raised(); }
 
-    bool fused_step = false;  // mrl_debug_set fused_step: one launch with the ticketed in-kernel prefix instead of two launches
+    bool fused_step = false;  // one launch with the self-healing in-kernel look-back (the default where the grid allows; mrl_debug_set fused_step 2: two launches)
 
     void step(const int32_t *actions, hipStream_t stream) override
     {
@@ -615,6 +615,7 @@ struct CartpoleSim final : mrl_sim {
 
     size_t action_elems() const override { return (size_t)num_worlds; }
     const char *kernel_name() const override { return fused_grid && fused_step ? "mrl_cartpole_step_fused" : "mrl_cartpole_step"; }
+    const char *rollout_kernel_name() const override { return persistent_ok && !launch_state.device_mode ? "mrl_cartpole_rollout" : kernel_name(); }
     uint64_t bytes_per_world_step() const override { return 44; }
 };
 

@@ -213,6 +213,7 @@ struct mrl_sim {
     virtual void reseed_shard(uint32_t, uint32_t, hipStream_t) {}
     virtual bool tensor(int slot, mrl_tensor_desc *out) = 0;
     virtual const char *kernel_name() const = 0;
+    virtual const char *rollout_kernel_name() const { return kernel_name(); }
     virtual uint64_t bytes_per_world_step() const = 0;
     // a bounded in-kernel wait expired in an earlier call: episode numbers are unspecified from there on
     virtual bool scan_timed_out() const { return false; }

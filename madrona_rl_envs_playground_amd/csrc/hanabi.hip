@@ -143,7 +143,13 @@ struct HanabiParams {
     do {                                                                                                          \
         if (p.stamps && lane == 0) p.stamps[(size_t)(bid * kWavesPerBlock) * 16 + 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+// the persistent rollout: its last step but one (row = wave 0..7, the scan wave in slots 8.. of wave 0)
+#define RSTAMP(row, slot)                                                                                         \
+    do {                                                                                                          \
+        if (p.stamps && lane == 0 && k + 2u == num_steps) p.stamps[(size_t)(b * kWavesPerBlock + (row)) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
+#define RSTAMP(row, slot) ((void)0)
 #define FSTAMP_SCAN(k) ((void)0)
 #define FSTAMP(k) ((void)0)
 #define STAMP(k) ((void)0)
@@ -1279,11 +1285,12 @@ __device__ __forceinline__ uint32_t recount_chunk(const HanabiParams &p, uint8_t
 
 // The scan wave's re-deal: the workgroup's finished worlds dealt anew IN their slots of the stepping waves' LDS (record and
 // both agents' bit vectors), 32 per round, in ascending world order: entry e is the (first_episode + e)-th episode
-// (entries of wave w: start_of[w] .. start_of[w + 1]; s_fin[w][i] = the wave's i-th finished world).  Their rows are
+// (entries of wave w: start_of[w] .. start_of[w + 1]; s_fin[w][i] = the wave's i-th finished world; slot_of(w) = where wave
+// w's worlds live in LDS).  Their rows are
 // written by the wave that owns the slot, at the end of its own stream of stores: from the scan wave every store would be
 // a round trip of its own through a saturated fabric (measured: 14 us for five worlds).
-template <int kV>
-__device__ __forceinline__ void deal_finished_worlds(const HanabiParams &p, uint8_t *smem, const uint8_t (*s_fin)[kWorldsPerWave],
+template <int kV, typename SlotOf>
+__device__ __forceinline__ void deal_finished_worlds(const HanabiParams &p, SlotOf slot_of, const uint8_t (*s_fin)[kWorldsPerWave],
                                                      const uint32_t (&start_of)[kWavesPerBlock + 1], uint32_t first_episode, uint32_t lane)
 {
     constexpr int kR = kV ? 5 : 0;
@@ -1300,7 +1307,7 @@ __device__ __forceinline__ void deal_finished_worlds(const HanabiParams &p, uint
             for (int w = 0; w < kWavesPerBlock; w++) first = wv == (uint32_t)w ? start_of[w] : first;
             local = (lane & 31u) < here ? s_fin[wv][e - first] : 0u;
         }
-        const WaveLds slot = wave_lds(smem, wv);
+        const WaveLds slot = slot_of(wv);
         uint8_t *rec = slot.rec + local * kRecStride;
         if (lane < here) deal_new_game<kR>(p, rec, first_episode + e0 + lane);
         wave_lds_sync();
@@ -1401,7 +1408,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             *reset_count = before + block_total;
             *next_counter = base + before + block_total;
         }
-        deal_finished_worlds<kV>(p, smem, s_fin, start_of, base + before, lane);
+        deal_finished_worlds<kV>(p, [&](uint32_t wv) { return wave_lds(smem, wv); }, s_fin, start_of, base + before, lane);
         if (lane == 0) __hip_atomic_store(&s_ready, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FSTAMP_SCAN(2);
         return;
@@ -1499,55 +1506,92 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
 // launches it cooperatively (the runtime refuses a grid the device cannot hold at once) and falls
 // back to one launch per step when that fails.  Waits are bounded as everywhere (SCAN_TIMEOUT).
 //
-// The workgroup is the single step's: four leader waves run phase A for 64 worlds each, all eight
-// stepping waves stream out their 32 worlds' rows, and the ninth -- the scan wave -- does both
-// hand-offs and deals the finished worlds anew in LDS meanwhile, so that neither the look-back nor
-// the ten dependent draws of a new game are in a stepping wave's instruction stream (with the
-// re-deal in the stepping waves a step took 20.3 us, as long as a launch per step).  A step ends
-// with a barrier: the next phase A rewrites the bit vectors phase B reads.
+// Thirteen waves with fixed jobs, coupled by three counters in LDS instead of barriers, so that phase A of step
+// k + 1 runs while the rows of step k are being stored:
+//   waves 0..3   phase A for 64 worlds each (slots w and w + 4), into bit-vector buffer k & 1;
+//   waves 4..11  phase B, 32 worlds each: the movers' rows, then the finished worlds' new rows.  (Eight of them:
+//                a wave expands and stores one 1 KB round per 0.33 us whatever the others do -- four waves with
+//                64 worlds each took 17 us over a step's rows, eight take 9.3.);
+//   wave  12     the scan wave: both hand-offs, and deals the finished worlds anew in LDS.
+// Step k:  A waits for dealt >= k (the records hold step k - 1's new games) and b_done >= 8 (k - 1) (phase B of
+// step k - 2 has read buffer k & 1); the scan wave and B wait for a_done >= 4 (k + 1); B's new rows wait for
+// dealt >= k + 1.  A counter is raised after the LDS traffic it announces (s_waitcnt lgkmcnt(0)); every raise is
+// reached whatever the other waves do (the scan wave's waits on other workgroups are the bounded ones), and the
+// dependencies above have no cycle.
+// Measured, 65536 worlds, us per step: the re-deal in the stepping waves, two barriers 20.3 (as long as a launch per
+// step); the single step's workgroup (leaders, scan wave, barriers between the phases) 15.3, HBM idle during every
+// phase A; this one 13.1.  What bounds it now is the chain  phase A 3.4 -> look-back -> deal 1.8 -> next phase A:
+// the look-back waits 8 us for the slowest LOWER workgroup's count (a workgroup whose stores are taken late is late
+// with everything), twice what the loads themselves cost (tools/stamps_hanabi_rollout.py).
 // ---------------------------------------------------------------------------------------------
 constexpr int kRing = 4;
+constexpr int kSlotRecBytes = kWorldsPerWave * kRecStride, kSlotEncBytes = kWorldsPerWave * 2 * kEncWords * 4;
+constexpr int kRolloutLdsBytes = kWavesPerBlock * (kSlotRecBytes + 2 * kSlotEncBytes);
+static_assert(kRolloutLdsBytes + 2048 <= 160 * 1024, "records + two bit-vector buffers fit a CU's LDS");
+constexpr int kRolloutBlock = 13 * kWave;  // 4 phase-A waves, 8 phase-B waves, the scan wave
+
+__device__ __forceinline__ WaveLds rollout_lds(uint8_t *smem, uint32_t slot, uint32_t buf)
+{
+    return WaveLds{smem + slot * kSlotRecBytes,
+                   reinterpret_cast<uint32_t *>(smem + kWavesPerBlock * kSlotRecBytes + (buf * kWavesPerBlock + slot) * kSlotEncBytes)};
+}
+__device__ __forceinline__ void flag_wait(uint32_t *flag, uint32_t at_least)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < at_least) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void flag_raise(uint32_t *flag, uint32_t lane)  // by one: every wave of a job raises it once per step
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <int kV>
-__global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(kRolloutBlock) __attribute__((amdgpu_waves_per_eu(4)))
 mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epoch0, uint32_t num_steps, uint32_t first_step,
                    const uint32_t *episode_base, uint32_t *next_counter, uint32_t *reset_count, const mrl::Alarm timed_out)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
-    __shared__ uint32_t s_counts[kWavesPerBlock];
-    __shared__ uint32_t s_dealt;  // the number of steps whose fresh games are in LDS
-    __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
-    __shared__ uint32_t s_overs[kWavesPerBlock], s_movers[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[kRolloutLdsBytes];
+    __shared__ uint32_t s_counts[2][kWavesPerBlock], s_overs[2][kWavesPerBlock], s_movers[2][kWavesPerBlock];  // by step parity, like the bit vectors
+    __shared__ uint8_t s_fin[2][kWavesPerBlock][kWorldsPerWave];
+    __shared__ uint32_t s_a_done, s_dealt, s_b_done;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const bool scan_wave = wib == (uint32_t)kWavesPerBlock;
     HanabiParams p = p0;
     const uint32_t N = p.num_worlds, G = gridDim.x, b = blockIdx.x;
-    const uint32_t w0 = b * kWorldsPerBlock + wib * kWorldsPerWave;
-    const uint32_t nw = (!scan_wave && w0 < N) ? min((uint32_t)kWorldsPerWave, N - w0) : 0u;
-    const WaveLds l = wave_lds(smem, scan_wave ? 0u : wib);
-    if (threadIdx.x == 0) s_dealt = 0u;
-    load_records(p, l, w0, nw, lane);
-    mrl::lds_barrier();  // every wave's records are in LDS (a leader steps its partner's worlds too)
+    const bool a_wave = wib < 4, scan_wave = wib == 12;  // the eight in between: phase B, slot wib - 4
+    if (threadIdx.x == 0) {
+        s_a_done = 0u;
+        s_dealt = 0u;
+        s_b_done = 0u;
+    }
+    const uint32_t b_slot = (wib - 4u) & 7u;
+    const uint32_t w0 = b * kWorldsPerBlock + b_slot * kWorldsPerWave;
+    const uint32_t nw = (!a_wave && !scan_wave && w0 < N) ? min((uint32_t)kWorldsPerWave, N - w0) : 0u;
+    load_records(p, rollout_lds(smem, b_slot, 0), w0, nw, lane);
+    mrl::lds_barrier();  // the only barrier: records and counters are in LDS
 
     if (scan_wave) {
         // ================= the scan wave =================
+        __builtin_amdgcn_s_setprio(3);  // (it and phase A are the chain that bounds a step; phase B shares their SIMDs)
         uint32_t base = *episode_base;  // first episode index of the current step
         for (uint32_t k = 0; k < num_steps; k++) {
-            const uint32_t epoch = epoch0 + k;
+            const uint32_t epoch = epoch0 + k, buf = k & 1u;
             unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
             const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
-            mrl::lds_barrier();  // phase A is through: s_counts and s_fin are there
-            uint32_t start_of[kWavesPerBlock + 1];
-            start_of[0] = 0;
-#pragma unroll
-            for (int w = 0; w < kWavesPerBlock; w++) start_of[w + 1] = start_of[w] + s_counts[w];
-            const uint32_t block_total = start_of[kWavesPerBlock];
-            if (lane == 0) mrl::publish_count(now, b, epoch, block_total);
             uint32_t lower = 0, prev_all = 0, unused = 0;
             if (k > 0)  // everybody's count of the previous step (published long ago)
                 for (uint32_t first = 0; first < G; first += kWave * 8u)
                     prev_all += mrl::read_counts<8>(before_step, first, G, epoch - 1u, 0u, &unused, timed_out);
+            RSTAMP(0, 8);
+            flag_wait(&s_a_done, 4u * (k + 1u));
+            RSTAMP(0, 9);
+            uint32_t start_of[kWavesPerBlock + 1];
+            start_of[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) start_of[w + 1] = start_of[w] + s_counts[buf][w];
+            const uint32_t block_total = start_of[kWavesPerBlock];
+            if (lane == 0) mrl::publish_count(now, b, epoch, block_total);
             if (block_total != 0)  // the lower workgroups' counts of this step
                 for (uint32_t first = 0; first < b; first += kWave * 8u) lower += mrl::read_counts<8>(now, first, b, epoch, 0u, &unused, timed_out);
             for (int off = 32; off > 0; off >>= 1) {
@@ -1555,9 +1599,10 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
                 prev_all += __shfl_xor(prev_all, off, 64);
             }
             base += prev_all;  // previous step's finished worlds, all workgroups (0 in the first step)
-            deal_finished_worlds<kV>(p, smem, s_fin, start_of, base + lower, lane);
-            if (lane == 0) __hip_atomic_store(&s_dealt, k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            mrl::lds_barrier();  // the step's end
+            RSTAMP(0, 10);
+            deal_finished_worlds<kV>(p, [&](uint32_t wv) { return rollout_lds(smem, wv, buf); }, s_fin[buf], start_of, base + lower, lane);
+            flag_raise(&s_dealt, lane);
+            RSTAMP(0, 11);
         }
         // the counter after the rollout: the last step's counts of everybody (the last workgroup has the
         // highest index, so these are "lower" counts plus its own and the usual wait applies)
@@ -1575,17 +1620,19 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
         return;
     }
 
-    // ================= the eight stepping waves =================
-    const bool leader = wib < 4;                        // waves w and w + 4 share a SIMD (mrl_hanabi_step_fused)
-    const uint32_t half = lane >> 5, idx = lane & 31u;
-    const uint32_t slot = wib + half * 4u;              // whose worlds this lane steps in phase A
-    const uint32_t a_w0 = b * kWorldsPerBlock + slot * kWorldsPerWave;
-    const uint32_t a_nw = (leader && a_w0 < N) ? min((uint32_t)kWorldsPerWave, N - a_w0) : 0u;
-    const WaveLds ls = wave_lds(smem, leader ? slot : wib);
-    const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
-    for (uint32_t k = 0; k < num_steps; k++) {
-        // ---- phase A: draw, act, encode the next mover ----
-        if (leader) {
+    if (a_wave) {
+        // ================= phase A: draw, act, encode the next mover =================
+        __builtin_amdgcn_s_setprio(3);
+        const uint32_t half = lane >> 5, idx = lane & 31u, slot = wib + 4u * half;
+        const uint32_t a_w0 = b * kWorldsPerBlock + slot * kWorldsPerWave, a_nw = a_w0 < N ? min((uint32_t)kWorldsPerWave, N - a_w0) : 0u;
+        for (uint32_t k = 0; k < num_steps; k++) {
+            const uint32_t buf = k & 1u;
+            RSTAMP(wib, 0);
+            if (k >= 1) flag_wait(&s_dealt, k);
+            RSTAMP(wib, 1);
+            if (k >= 2) flag_wait(&s_b_done, 8u * (k - 1u));
+            RSTAMP(wib, 2);
+            const WaveLds ls = rollout_lds(smem, slot, buf);
             p.sample_step = first_step + k;
             bool over = false, next_is_1 = false;
             if (idx < a_nw) {
@@ -1605,27 +1652,38 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
             }
             const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
             const uint32_t my_overs = (uint32_t)(half ? all_overs >> 32 : all_overs), my_movers = (uint32_t)(half ? all_movers >> 32 : all_movers);
-            if (over) s_fin[slot][__popc(my_overs & ((1u << idx) - 1u))] = (uint8_t)idx;
+            if (over) s_fin[buf][slot][__popc(my_overs & ((1u << idx) - 1u))] = (uint8_t)idx;
             if (idx == 0) {
-                s_counts[slot] = (uint32_t)__popc(my_overs);
-                s_overs[slot] = my_overs;
-                s_movers[slot] = my_movers;
+                s_counts[buf][slot] = (uint32_t)__popc(my_overs);
+                s_overs[buf][slot] = my_overs;
+                s_movers[buf][slot] = my_movers;
             }
+            flag_raise(&s_a_done, lane);
+            RSTAMP(wib, 3);
         }
-        mrl::lds_barrier();  // hands the finished worlds to the scan wave (and a partner's ballots back to it)
-        const unsigned long long overs = s_overs[wib], movers = s_movers[wib];
-        const uint32_t mine = (uint32_t)__popcll(overs);
-
-        // ---- phase B: the movers' rows of the worlds that go on; then the finished worlds' new rows ----
-        expand_movers(p, l, nw, overs, movers, out, lane);
-        if (mine != 0) {
-            while (__hip_atomic_load(&s_dealt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= k) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            store_fresh_rows(p, l, s_fin[wib], mine, w0, lane);
-        }
-        mrl::lds_barrier();  // the step's end: the next phase A rewrites what phase B and the scan wave have read
+        return;
     }
-    store_records(p, l, w0, nw, lane);
+
+    // ================= phase B: the movers' rows of the worlds that go on; then the finished worlds' new rows =================
+    const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
+    for (uint32_t k = 0; k < num_steps; k++) {
+        const uint32_t buf = k & 1u;
+        const WaveLds l = rollout_lds(smem, b_slot, buf);
+        RSTAMP(b_slot, 4);
+        flag_wait(&s_a_done, 4u * (k + 1u));
+        RSTAMP(b_slot, 5);
+        const uint32_t overs = s_overs[buf][b_slot];
+        expand_movers(p, l, nw, overs, s_movers[buf][b_slot], out, lane);
+        RSTAMP(b_slot, 6);
+        if (overs != 0) {
+            flag_wait(&s_dealt, k + 1u);
+            store_fresh_rows(p, l, s_fin[buf][b_slot], (uint32_t)__popc(overs), w0, lane);
+        }
+        flag_raise(&s_b_done, lane);
+        RSTAMP(b_slot, 7);
+    }
+    flag_wait(&s_dealt, num_steps);  // the last step's new games are in the records
+    store_records(p, rollout_lds(smem, b_slot, 0), w0, nw, lane);
 }
 
 __global__ void fill_agent_ids(int32_t *world_id, int32_t *agent_id, uint32_t n)
@@ -1694,7 +1752,7 @@ struct HanabiSim final : mrl_sim {
         uint32_t *next = counter + (parity ^ 1u);
         mrl::Alarm al = alarm.alarm();
         void *args[] = {&a, &ring, &epoch0, &num_steps, &first_step, &base, &next, &reset_count, &al};
-        const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_hanabi_rollout<kV>), dim3(grid), dim3(kFusedBlock),
+        const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_hanabi_rollout<kV>), dim3(grid), dim3(kRolloutBlock),
                                                           args, 0, stream);
         if (err != hipSuccess) {
             (void)hipGetLastError();
@@ -1836,6 +1894,7 @@ struct HanabiSim final : mrl_sim {
 
     size_t action_elems() const override { return (size_t)2 * num_worlds; }
     const char *kernel_name() const override { return fused ? "mrl_hanabi_step_fused" : "mrl_hanabi_step"; }
+    const char *rollout_kernel_name() const override { return persistent_ok && !launch_state.device_mode ? "mrl_hanabi_rollout" : kernel_name(); }
 
     uint64_t bytes_per_world_step() const override
     {
@@ -1954,7 +2013,7 @@ mrl_sim *mrl::create_hanabi(const mrl_hanabi_config *cfg, int gpu_id, uint32_t n
             const void *fn = sim->variant == 2 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<2>)
                              : sim->variant == 1 ? reinterpret_cast<const void *>(&mrl_hanabi_rollout<1>)
                                                  : reinterpret_cast<const void *>(&mrl_hanabi_rollout<0>);
-            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kFusedBlock, 0));
+            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kRolloutBlock, 0));
             MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
             // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
             // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)

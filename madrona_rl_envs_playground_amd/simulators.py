@@ -294,6 +294,11 @@ class _Simulator:
         return self._L.mrl_kernel_name(self._handle).decode()
 
     @property
+    def rollout_kernel_name(self):
+        """The kernel the next ``rollout_random`` runs (a persistent one, or the step kernel once per step)."""
+        return self._L.mrl_rollout_kernel_name(self._handle).decode()
+
+    @property
     def bytes_per_world_step(self):
         return int(self._L.mrl_bytes_per_world_step(self._handle))
 

@@ -194,6 +194,7 @@ def test_device_random_policy(n, steps, hip_lib):
     c.step()  # the episode counter after a rollout continues like after single steps
     a.step()
     assert torch.equal(c.observation_tensor().to_torch(), a.observation_tensor().to_torch())
+    assert c.rollout_kernel_name == "mrl_cartpole_rollout", "the runtime refused the cooperative launch: these were launches per step"
     for sim in (a, b, c):
         assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
         sim.close()

@@ -241,6 +241,7 @@ def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib):
     one = make(cfg, n)
     with debug_knobs({"hanabi.no_persistent": 1}):
         many = make(cfg, n)
+    assert one.rollout_kernel_name == "mrl_hanabi_rollout" and many.rollout_kernel_name == many.kernel_name
     names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor",
              "done_tensor", "game_tensor", "reset_count_tensor", "action_tensor"]
     step = 0
@@ -258,6 +259,7 @@ def test_persistent_rollout_equals_stepwise(cfg, n, hip_lib):
         sim.step()
     assert torch.equal(one.game_tensor().to_torch(), many.game_tensor().to_torch())
     assert int(one.scan_timeout_tensor().to_torch().item()) == 0
+    assert one.rollout_kernel_name == "mrl_hanabi_rollout", "the runtime refused the cooperative launch: these were launches per step"
     one.close()
     many.close()
 

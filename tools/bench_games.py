@@ -65,8 +65,10 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     dev = e0.elapsed_time(e1) / args.steps * 1e-3
-    out["hanabi"].update({"us_per_step_device_policy": dev * 1e6, "steps_per_s_device_policy": n / dev,
-                          "algorithmic_GBps_device_policy": sim.bytes_per_world_step * n / dev / 1e9})
+    persistent = sim.rollout_kernel_name == "mrl_hanabi_rollout"
+    roll_bytes = sim.bytes_per_world_step - (2 * 176 if persistent else 0)  # (the records stay in LDS between the steps)
+    out["hanabi"].update({"us_per_step_device_policy": dev * 1e6, "steps_per_s_device_policy": n / dev, "rollout_kernel": sim.rollout_kernel_name,
+                          "device_policy_bytes_per_world_step": roll_bytes, "algorithmic_GBps_device_policy": roll_bytes * n / dev / 1e9})
     sim.close()
 
     n = args.cartpole_worlds

@@ -29,8 +29,10 @@ def main():
         a.rollout_random(k, seed=5, first_step=done)
         b.rollout_random(k, seed=5, first_step=done)
         done += k
-        assert torch.equal(a.game_tensor().to_torch(), b.game_tensor().to_torch()), f"hanabi records differ after {done} steps"
-    assert torch.equal(a.observation_tensor().to_torch(), b.observation_tensor().to_torch())
+        for name in ("game_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor", "done_tensor",
+                     "action_tensor", "reset_count_tensor"):
+            assert torch.equal(getattr(a, name)().to_torch(), getattr(b, name)().to_torch()), f"hanabi {name} differs after {done} steps"
+    assert a.rollout_kernel_name == "mrl_hanabi_rollout" and b.rollout_kernel_name == b.kernel_name
     assert int(a.scan_timeout_tensor().to_torch().item()) == 0 and int(b.scan_timeout_tensor().to_torch().item()) == 0
     print("hanabi", done, "steps x 65536 worlds: persistent == per-step launches")
     a.close(); b.close()
