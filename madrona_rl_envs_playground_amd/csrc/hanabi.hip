@@ -908,37 +908,42 @@ __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t row, uint32_t b
     __builtin_amdgcn_raw_buffer_store_b128(r, row, (int)byte_offset, 0, 16);  // aux bit 4 = sc1
 }
 
-__device__ __forceinline__ uint32_t spread4(uint32_t bits)
+__device__ __forceinline__ uint32_t spread4(uint32_t nibble)
 {
     // 4 bits -> 4 bytes of 0/1 (the shifted copies do not overlap, so no carries)
-    return ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+    return (nibble * 0x00204081u) & 0x01010101u;
 }
 
 // Phase B: chunk `ch` (16 bytes) of one agent block from that agent's bit vector.  Chunks 0..48 are the
 // state row (whose first 658 bytes are the observation), 49..53 the legal-move mask as five int32x4,
-// 54..55 padding up to whole cache lines.
-__device__ __forceinline__ uint32_t clip16(uint32_t raw, uint32_t first, uint32_t limit)
+// 54..55 padding up to whole cache lines.  Straight-line code: a state chunk spreads four nibbles of a 16-bit
+// piece of the bit vector into four bytes each, a mask chunk four single bits of the legal-move word into one
+// int32 each -- the same  shift, mask, spread  with a different stride (4 or 1) and mask (0xF or 1), chosen per lane
+// by selects.  (Written as `is_state ? spread4(..) : bit`, hipcc compiled ten divergent branches per chunk, and
+// the three LDS reads of a chunk were waited for before anything else was issued: 0.30 us per 1 KB store and wave,
+// whatever HBM was doing -- tools/stamps_hanabi_rollout.py.)
+struct ChunkSource {
+    uint32_t word, legal, shift;  // the 32 bits holding the chunk's piece, the legal-move word, how far the encoding was shifted
+};
+__device__ __forceinline__ ChunkSource chunk_source(const uint32_t *enc, uint32_t ch)
 {
-    // bits of [first, first + 16) that lie below `limit`
-    const int32_t room = (int32_t)limit - (int32_t)first;
-    return room >= 16 ? raw : (room <= 0 ? 0u : raw & ((1u << room) - 1u));
+    return ChunkSource{enc[min(ch >> 1, 24u)], enc[25], enc[26]};
 }
-
-// (component-wise throughout: a select between two uint4 values makes hipcc park them in scratch memory)
-__device__ __forceinline__ uint4 agent_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t ch)
+__device__ __forceinline__ uint4 chunk_bytes(const HanabiParams &p, const ChunkSource &c, uint32_t ch)
 {
-    const uint32_t word = enc[min(ch >> 1, 24u)];  // 16-bit piece `ch` of the bit vector (meaningless behind the state row)
-    const uint32_t legal = enc[25];
     // the row is MRL_HANABI_STATE_SIZE wide whatever the configuration; what the shifted encoding pushes past
-    // its end is dropped (the reference writes it out of bounds)
-    const uint32_t limit = min(p.state_bits + enc[26], (uint32_t)MRL_HANABI_STATE_SIZE);
-    const uint32_t piece = clip16((word >> ((ch & 1u) * 16u)) & 0xFFFFu, ch * 16u, limit);
+    // its end is dropped (the reference writes it out of bounds): keep the bits of [16 ch, 16 ch + 16) below `limit`
+    const uint32_t limit = min(p.state_bits + c.shift, (uint32_t)MRL_HANABI_STATE_SIZE);
+    const int32_t room = (int32_t)limit - (int32_t)(ch * 16u);
+    const uint32_t keep = (1u << (uint32_t)min(max(room, 0), 16)) - 1u;
+    const uint32_t piece = (c.word >> ((ch & 1u) * 16u)) & keep;
     const bool is_state = ch < (uint32_t)kStateChunks;
-    const uint32_t m = ch - kStateChunks;  // mask chunk 0..4, padding behind
-    const uint32_t bits = (!is_state && m < (uint32_t)kMaskChunks) ? legal >> (4u * m) : 0u;
-    return make_uint4(is_state ? spread4(piece) : (bits & 1u), is_state ? spread4(piece >> 4) : ((bits >> 1) & 1u),
-                      is_state ? spread4(piece >> 8) : ((bits >> 2) & 1u), is_state ? spread4(piece >> 12) : ((bits >> 3) & 1u));
+    const uint32_t m = min(ch - (uint32_t)kStateChunks, (uint32_t)kMaskChunks);  // mask chunk 0..4; 5 = padding (and state chunks: unused)
+    const uint32_t bits = (c.legal >> (4u * m)) & (m < (uint32_t)kMaskChunks ? 0xFu : 0u);
+    const uint32_t src = is_state ? piece : bits, stride = is_state ? 4u : 1u, nib = is_state ? 0xFu : 1u;
+    return make_uint4(spread4(src & nib), spread4((src >> stride) & nib), spread4((src >> (2u * stride)) & nib), spread4((src >> (3u * stride)) & nib));
 }
+__device__ __forceinline__ uint4 agent_chunk(const HanabiParams &p, const uint32_t *enc, uint32_t ch) { return chunk_bytes(p, chunk_source(enc, ch), ch); }
 
 struct WaveLds {
     uint8_t *rec;    // kWorldsPerWave x kRecStride
@@ -955,17 +960,27 @@ __device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
 
 // Phase B for a wave's movers: the 56 chunks of an agent block times the wave's worlds, 64 chunks per store -- 28 full-width
 // stores for 32 worlds.  Chunk f of that run belongs to world f / 56 (a multiply-shift) and is chunk f % 56 of its block.
-__device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveLds &l, uint32_t nw, unsigned long long overs,
-                                              unsigned long long movers, __amdgpu_buffer_rsrc_t out, uint32_t lane)
+__device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveLds &l, uint32_t nw, uint32_t overs, uint32_t movers,
+                                              __amdgpu_buffer_rsrc_t out, uint32_t lane)
 {
     const uint32_t total = nw * kAgentChunks;  // <= 1792
+    const uint32_t rounds = (total + kWave - 1u) / kWave;  // wave-uniform: the loop runs on a scalar counter
+    // (f / 56 by multiply-shift, exact for f < 4096; lanes behind the run read world 31's words and store nothing)
+    auto source_of = [&](uint32_t f) {
+        const uint32_t r = min((f * 2341u) >> 17, (uint32_t)kWorldsPerWave - 1u);
+        return chunk_source(l.enc + r * 2 * kEncWords, f - r * kAgentChunks);
+    };
+    ChunkSource next = source_of(lane);
 #pragma unroll 2
-    for (uint32_t f = lane; f < total + lane; f += kWave) {  // uniform trip count; lanes behind the run store nothing
-        const uint32_t r = (f * 2341u) >> 17;  // f / 56, exact for f < 4096
+    for (uint32_t i = 0; i < rounds; i++) {
+        const uint32_t f = i * kWave + lane;
+        const ChunkSource cur = next;
+        next = source_of(f + kWave);  // requested before this round's arithmetic
+        const uint32_t r = min((f * 2341u) >> 17, (uint32_t)kWorldsPerWave - 1u);
         const uint32_t ch = f - r * kAgentChunks;
-        const uint4 v = agent_chunk(p, l.enc + r * 2 * kEncWords, ch);  // (r <= 31: inside the wave's LDS whatever nw is)
-        const uint32_t agent = (uint32_t)(movers >> r) & 1u;
-        const bool skip = f >= total || ((overs >> r) & 1ull);  // a finished world's rows come from the re-deal
+        const uint4 v = chunk_bytes(p, cur, ch);
+        const uint32_t agent = (movers >> r) & 1u;
+        const bool skip = f >= total || ((overs >> r) & 1u);  // a finished world's rows come from the re-deal
         const uint32_t at = skip ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;  // out of range = dropped by the descriptor
         row_store(out, at, v);
     }
