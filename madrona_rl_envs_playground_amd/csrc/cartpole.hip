@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
 // workgroup ever depends on another one making progress) and are written once, already re-seeded;
 // the two-launch pair above stays for the sharded path, whose episode base comes from the other
 // ranks between the phases.  A workgroup stores its worlds' state only after its count is globally
-// visible (the __syncthreads behind the publication waits for it).
+// visible (the publishing wave waits for its store before the barrier everybody passes).
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
                                                                   int32_t *__restrict__ done, unsigned long long *status,
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
                                                                   const mrl::HealTest heal, const mrl::DeviceCounter device_counter)
 {
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_votes[kUnroll][kBlock / 64];
     __shared__ uint32_t s_prefix;
     const uint32_t b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
@@ -289,28 +289,45 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
             a[u] = action[ic];
         }
     }
+    // the finished worlds, as one ballot per round and wave (round u covers worlds first + 256 u ...: ascending world
+    // order = round, then wave, then lane); every hand-off below goes through LDS only -- a __syncthreads would also
+    // wait for the wave's outstanding stores to be acknowledged, microseconds while the whole GPU is storing
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool over[kUnroll];
-    uint32_t finished = 0;
+    unsigned long long votes[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
         over[u] = i < last && advance(s[u], a[u]);
-        finished += over[u] ? 1u : 0u;
+        votes[u] = __ballot(over[u]);
+        if (lane == 0) s_votes[u][wave] = (uint32_t)__popcll(votes[u]);
     }
-    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
-    __syncthreads();
-    uint32_t block_total = 0;
-    for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
-    if (threadIdx.x == 0) mrl::publish_count(status, b, epoch, block_total);
-    __syncthreads();  // the count is globally visible (vmcnt(0) in front of the barrier); s_wave is reused below
+    mrl::lds_barrier();
+    uint32_t block_total = 0, before_me[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+        before_me[u] = block_total;
+        for (uint32_t w = 0; w < kBlock / 64; w++) {
+            const uint32_t c = s_votes[u][w];
+            before_me[u] += w < wave ? c : 0u;
+            block_total += c;
+        }
+        before_me[u] += (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
+    }
+    // the count is globally visible before any wave of this workgroup overwrites a world's state (a healing workgroup
+    // that does not see the count reads the state as the step's input): the publishing wave waits for ITS stores only
+    if (wave == 0) {
+        if (lane == 0) mrl::publish_count(status, b, epoch, block_total);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    mrl::lds_barrier();
     // the first wave looks back BEFORE its own stores (a load would otherwise sit out their acknowledgement) ...
-    if (threadIdx.x < 64 && (block_total != 0 || last_block)) {
+    if (wave == 0 && (block_total != 0 || last_block)) {
         const bool sampled = action_out != nullptr;
         const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
             return recount_chunk(n, action, state, j, sampled, sample_seed, sample_step);
         });
-        if (threadIdx.x == 0) s_prefix = before;
+        if (lane == 0) s_prefix = before;
     }
     // ... while everything that does not need the prefix goes out
 #pragma unroll
@@ -324,17 +341,12 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     }
     if (block_total == 0 && !last_block) return;  // uniform per workgroup
     mrl::lds_barrier();
-    uint32_t running = s_prefix;
-    const uint32_t grand_total = running + block_total;  // the whole GPU's, in the last workgroup
+    const uint32_t prefix = s_prefix;
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) {  // ascending world order: round u covers worlds first + 256 u ...
-        uint32_t total;
-        const uint32_t rank = block_rank(over[u], s_wave, total);
-        if (over[u]) state[first + u * kBlock + threadIdx.x] = fresh_state(base + running + rank);
-        running += total;
-        __syncthreads();
-    }
+    for (int u = 0; u < kUnroll; u++)
+        if (over[u]) state[first + u * kBlock + threadIdx.x] = fresh_state(base + prefix + before_me[u]);
     if (last_block && threadIdx.x == 0) {
+        const uint32_t grand_total = prefix + block_total;  // the whole GPU's
         *reset_count = grand_total;
         *next_counter = base + grand_total;
     }

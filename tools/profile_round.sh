@@ -38,6 +38,7 @@ python tools/scaling_tables.py > $out/${tag}_scaling_tables.json 2>/dev/null
 echo "games / loops done"
 make -C madrona_rl_envs_playground_amd/csrc -j16 diag > $out/${tag}_diag_build.log 2>&1
 python tools/stamps_hanabi_fused.py > $out/${tag}_hanabi_fused_timeline.txt 2>&1
+python tools/stamps_hanabi_rollout.py > $out/${tag}_hanabi_rollout_timeline.txt 2>&1
 python tools/stamps.py > $out/${tag}_overcooked_wave_timeline.txt 2>&1
 python tools/graph_probe.py > $out/${tag}_graph_probe.txt 2>&1
 echo "all done"
