@@ -8,6 +8,10 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
+# the PMC traffic table first: bench.py quotes profiles/step_traffic.json when its csrc hash is the running library's
+timeout -k 10 600 python3 tools/pmc_traffic.py $out/${tag}_traffic > $out/${tag}_traffic.log 2>&1
+cp $out/${tag}_traffic/step_traffic.json profiles/step_traffic.json
+echo "pmc traffic done"
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "bench done"; head -c 400 $out/${tag}_bench.json; echo
 MRL_BENCH_FORCE_DIST=1 python bench.py --gpus 1 --steps 500 --warmup 20 > $out/${tag}_bench_nccl_world_size_1.json 2>> $out/${tag}_bench.err
@@ -19,7 +23,6 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_cartpole_kt -o kt -- python3 $root/tools/prof_step.py --game cartpole --worlds 1048576 --steps 300 > $out/${tag}_cartpole_kt.log 2>&1
 echo "kernel traces done"
 cd $root
-timeout -k 10 600 python3 tools/pmc_traffic.py $out/${tag}_traffic > $out/${tag}_traffic.log 2>&1
 bash tools/pmc_passes.sh hanabi 65536 $out/${tag}_hanabi_pmc
 python tools/pmc_summary.py $out/${tag}_hanabi_pmc --match mrl_hanabi > $out/${tag}_hanabi_pmc.txt
 bash tools/pmc_passes.sh overcooked 32768 $out/${tag}_pmc
