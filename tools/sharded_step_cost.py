@@ -33,7 +33,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        # (RCCL prints its version banner on stdout when the first communicator comes up: stdout carries the JSON only)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     out = {"process_group": "nccl, world_size 1" if with_group else "none"}
     games = (("hanabi", 65536, lambda k: HanabiSimulator(ExecMode.CUDA, 0, k, 5, 5, 2, 8, 3)),
              ("cartpole", 1 << 20, lambda k: CartpoleSimulator(ExecMode.CUDA, 0, k)))
