@@ -15,7 +15,8 @@ shift-left of removeFromHand (:567-594), the deal (rng.hpp:7-36, drawDeck :45-52
 Information tokens may exceed their maximum: completing a firework adds one unconditionally (sim.cpp:676-678), the
 reference then writes a longer thermometer with its running offset (:119-125) and every later section moves up; what no
 longer fits the 658 / 783 entries of a row is cut off here (the reference writes it past the end of its array).  The game
-is never over in a script.
+is never over in a `script_*`; the endings -- checkDone (:812-850), the reward of a lost game, the re-deal of resetWorld with
+the next episode index and BOTH agents' fresh rows -- are what `run_policy_games` plays through, many episodes per world.
 """
 import numpy as np
 
@@ -55,7 +56,7 @@ class Game:
         self.fireworks = [0] * K
         self.discards = [0] * (K * R)
         self.info, self.life = MAX_INFO, MAX_LIFE
-        self.mover, self.turns_to_play = 0, 2
+        self.mover, self.turns_to_play, self.score = 0, 2, 0
         self.last = dict(move=NONE, player=-1, target=-1, index=-1, colour=-1, rank=-1, reveal=0, scored=False, info_token=False)
 
     def draw(self):
@@ -140,6 +141,13 @@ class Game:
 
     def hint_rank(self, rank):
         self._hint(REVEAL_RANK, rank)
+
+    def check_done(self):
+        """checkDone (sim.cpp:812-850) -> (reward of both agents, game over): the score is the fireworks' sum, or NOTHING once the
+        last life token is gone -- the move that loses the game is paid minus everything scored so far."""
+        old = self.score
+        self.score = sum(self.fireworks) if self.life > 0 else 0
+        return self.score - old, self.life < 1 or self.score >= K * R or self.turns_to_play <= 0
 
     def action_id(self, kind, value):
         """uid of the reference's action enumeration: 0-4 discard slot, 5-9 play slot, 10-14 reveal colour, 15-19 reveal rank."""
@@ -330,3 +338,60 @@ def script_complete_a_firework(episode, max_moves=140, after=4):
             if countdown == 0:
                 return steps
     return None
+
+
+# ---- whole games, endings included: every world follows a rule the script can evaluate (it sees all cards) ----
+def policy_score_then_lose(g):
+    """Play a playable card while nothing has been scored, then play cards that do not fit until the third life token is gone:
+    games of four to eight moves that end with life_tokens < 1 and, usually, a reward of minus the score."""
+    me = g.hands[g.mover]
+    playable = [s for s in range(me.size) if g.fireworks[me.cards[s] // R] == me.cards[s] % R]
+    wrong = [s for s in range(me.size) if s not in playable]
+    if sum(g.fireworks) == 0 and playable:
+        return "play", playable[0]
+    return ("play", wrong[0]) if wrong else ("play", playable[0])
+
+
+def policy_run_out_the_deck(g):
+    """Discard the first card when a token is missing, otherwise name the colour of the partner's first card: forty redraws
+    empty the deck, then every move counts turns_to_play down and the game ends with turns_to_play <= 0 and hands one card short."""
+    if g.info < MAX_INFO:
+        return "discard", 0
+    return "hint_colour", g.hands[1 - g.mover].cards[0] // R
+
+
+def run_policy_games(sim_step, read, n, policy, steps):
+    """n worlds of a FRESH simulator (world w plays episode w, the next episode is n) follow `policy` for `steps` steps.
+    `sim_step(actions (2, n) int32)`; `read()` -> (obs (2, n, 658), state (2, n, 783), mask (2, n, 20), active (2, n), done (n,),
+    reward (2, n)).  After every step: reward and done of every world; for a world that goes on the mover's rows as in
+    run_scripts; for a world whose game ended BOTH agents' rows of its next game, dealt from the episode index it gets
+    when finished worlds take the indices in ascending world order.  Returns (episodes started, set of ending reasons)."""
+    games = [Game(w) for w in range(n)]
+    next_episode, reasons = n, set()
+    for t in range(steps):
+        acts = np.zeros((2, n), np.int32)
+        for w, g in enumerate(games):
+            kind, value = policy(g)
+            acts[g.mover, w] = g.action_id(kind, value)
+            getattr(g, kind)(value)
+        sim_step(acts)
+        obs, state, mask, active, done, reward = read()
+        for w in range(n):  # ascending: the order in which finished worlds are given their episode indices
+            g = games[w]
+            rew, over = g.check_done()
+            assert reward[0, w] == rew and reward[1, w] == rew, f"world {w}, step {t}: reward {reward[:, w]} against {rew} by hand"
+            assert bool(done[w]) == over, f"world {w}, step {t}: done"
+            if over:
+                reasons.add("life" if g.life < 1 else "score" if g.score >= K * R else "turns")
+                g = games[w] = Game(next_episode)
+                next_episode += 1
+                views = (0, 1)
+            else:
+                views = (g.mover,)
+            assert active[g.mover, w] == 1 and active[1 - g.mover, w] == 0, f"world {w}, step {t}: active agent"
+            for me in views:
+                where = f"world {w}, step {t}, agent {me}" + (f" of the new game (episode {next_episode - 1})" if over else "")
+                assert np.array_equal(obs[me, w].astype(np.uint8), g.observation(me)[:658]), where + ": observation"
+                assert np.array_equal(state[me, w, :783].astype(np.uint8), g.state(me)), where + ": state"
+                assert np.array_equal(mask[me, w], g.legal(me)), where + ": legal moves"
+    return next_episode - n, reasons

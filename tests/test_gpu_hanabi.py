@@ -289,6 +289,29 @@ def test_known_answers_by_hand_on_gpu(script, n, hip_lib):
         sim.close()
 
 
+@pytest.mark.parametrize("policy,n,steps,reason", [("policy_score_then_lose", 600, 40, "life"), ("policy_run_out_the_deck", 300, 90, "turns")])
+def test_endings_and_next_episodes_by_hand_on_gpu(policy, n, steps, reason, hip_lib):
+    """Whole games worked out by hand (tests/hanabi_by_hand.py, not the oracle), endings included: every step's reward and
+    done -- the move that burns the last life token is paid minus the score --, and after an ending BOTH agents' rows of the
+    world's next game, dealt from the episode index it gets when the step's finished worlds (several workgroups' worth) take
+    the indices in ascending world order; through the single-launch step and through the two-launch pair."""
+    import hanabi_by_hand as by_hand
+    for knob in (1, 2):
+        with debug_knobs({"fused_step": knob}):
+            sim = make(FULL, n)
+
+        def step(acts):
+            sim.step_with_actions(torch.from_numpy(acts).cuda().view(2, n, 1).contiguous())
+
+        def read():
+            return tuple(getattr(sim, name)().to_torch().cpu().numpy() for name in
+                         ("observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "done_tensor", "reward_tensor"))
+        started, reasons = by_hand.run_policy_games(step, read, n, getattr(by_hand, policy), steps)
+        assert reasons == {reason} and started >= n
+        assert int(sim.reset_count_tensor().to_torch().item()) >= 0
+        sim.close()
+
+
 @pytest.mark.parametrize("n", [70001, 300])
 def test_phase_a_pairings_agree(n, hip_lib):
     """The single-launch step runs phase A in four "leader" waves on all 64 lanes (their own worlds and a partner wave's);

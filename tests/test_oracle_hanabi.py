@@ -302,3 +302,16 @@ def test_completed_firework_and_ninth_token_known_answers_by_hand(oracle_lib):
     assert (by_hand.PLAY, True, True, True) in kinds                      # the completing play, seen with nine tokens
     assert any(k[3] and k[0] != by_hand.PLAY for k in kinds) or any(k[3] and not k[2] for k in kinds)  # a later move seen shifted
     assert any(k[0] == by_hand.REVEAL_COLOUR and not k[3] for k in kinds)
+
+
+@pytest.mark.parametrize("policy,steps,reason", [("policy_score_then_lose", 60, "life"), ("policy_run_out_the_deck", 100, "turns")])
+def test_endings_and_next_episodes_by_hand(policy, steps, reason, oracle_lib):
+    """Whole games by hand, endings included (checkDone, sim.cpp:812-850; resetWorld :446-532): the reward of every step -- the
+    move that burns the last life token is paid MINUS the score so far --, done, and after an ending both agents' rows of
+    the world's next game, dealt from the episode index it gets when finished worlds take the indices in ascending world order."""
+    import hanabi_by_hand as by_hand
+    n = 40
+    orc = oracle_lib.HanabiOracle(CONFIGS["full"], n)
+    io = (lambda acts: orc.step(acts)), (lambda: (orc.obs, orc.state, orc.mask, orc.active, orc.done, orc.reward))
+    started, reasons = by_hand.run_policy_games(*io, n, getattr(by_hand, policy), steps)
+    assert reasons == {reason} and started >= n
