@@ -24,6 +24,9 @@ Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barri
 `torch.cuda.synchronize()` on both sides, max over ranks.  One block is the contract; when K steps
 are shorter than 50 ms (K = 20 is 0.2 ms here) the block is repeated and the MEDIAN block is
 reported (`timing.blocks` says how many), so that one scheduling hiccup is not the result.
+`timing.empty_block_ms` is what a block of no steps costs between the same two fences -- the bracket's
+share of a short block (at --steps 20 it is 6 % of the block on one GPU, more with the ranks' rendezvous
+in it); it is reported, never subtracted.
 
 Also on the line: `roofline` (algorithmic HBM bytes of the step kernel / its average launch duration,
 HIP events on the launch stream over >= 300 back-to-back launches; spec and on-box measured peaks),
@@ -279,8 +282,15 @@ def run(args):
     pool = [torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(args.pool)]
     obs = sim.observation_world_major_tensor().to_torch()
 
+    fence_token = torch.zeros(1, device="cuda") if use_dist and not rehearse else None
+
     def fence():
-        if use_dist:
+        """barrier + torch.cuda.synchronize().  Over RCCL the barrier is a one-element all_reduce enqueued behind the steps and waited
+        for by the synchronize -- the rendezvous dist.barrier() makes, without ProcessGroupNCCL::barrier's own host-side waits
+        (22 against 31 us per fence on an idle GPU, tools/fence_cost.py; the trailing fence is inside the timed block)."""
+        if fence_token is not None:
+            dist.all_reduce(fence_token)
+        elif use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,6 +334,10 @@ def run(args):
     # ---------------- headline: one launch per step, no communication ----------------
     blocks, mine = timed_blocks(lambda i: sim.step_with_actions(pool[i % args.pool]), args.steps, args.warmup)
     dt = statistics.median(blocks)
+    # what a block of NO steps costs between the same fences: the share of a short block (--steps 20) that is the contract's
+    # bracket, not the steps -- reported, never subtracted
+    empty_blocks, _ = timed_blocks(lambda i: None, 0, 0, max_blocks=9)
+    empty_block_ms = statistics.median(empty_blocks) * 1e3
     per_rank_ms = all_ranks(statistics.median(mine) / args.steps * 1e3)
 
     # ---------------- N > 1: the step followed by the all-gather of the observation shards ----------------
@@ -518,7 +532,7 @@ def run(args):
             "config": {"workload": f"Overcooked {args.layout}, {n} worlds per GPU, horizon {args.horizon}, "
                                    f"uniform random actions (pre-sampled pool of {args.pool}, resident in HBM)",
                        "worlds_per_gpu": n, "obs_gather": False},
-            "timing": {"blocks": len(blocks), "block_ms": [b * 1e3 for b in blocks], "reported": "median block",
+            "timing": {"blocks": len(blocks), "block_ms": [b * 1e3 for b in blocks], "reported": "median block", "empty_block_ms": empty_block_ms,
                        "per_rank_ms_per_step": per_rank_ms, "rank_min_ms_per_step": min(per_rank_ms), "rank_max_ms_per_step": max(per_rank_ms)},
             "roofline": roofline,
         }
