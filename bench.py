@@ -35,8 +35,8 @@ reference harness's own two timed regions, `wrapped_n_step` (scripts/overcooked_
 and `isolated_with_copies` (scripts/overcooked_isolated_example.py:56-65), and `other_configs`: the other
 BASELINE.json configurations one GPU can run -- Cartpole 1024 worlds (configs[0]) and 1 M worlds, Hanabi
 65536 worlds (configs[2]: scripts/hanabi_example.py:62-80), the four other standard layouts at the 32768-world
-shard of configs[3] -- each with its kernel, average launch duration over >= 300 launches, algorithmic bytes
-per world-step and roofline fraction.
+shard of configs[3], and the two sibling worlds (Simplecooked `simple` 32768 worlds, balance beam 1 M worlds) -- each with
+its kernel, average launch duration over >= 300 launches, algorithmic bytes per world-step and roofline fraction.
 
 `roofline.traffic` (and `traffic` of the other legs) are HBM bytes per launch from rocprofv3 PMC passes, which
 cannot run inside this process: they come from profiles/step_traffic.json and are quoted only when that file's
@@ -190,6 +190,28 @@ def other_configs(args, torch, local_rank, launches_us):
                                    note="kernel_us_avg = time per step call back to back; at 1024 worlds that is the host's call rate, not the kernel" if n == 1024 else None)
         sim.close()
         del pool
+
+    # the sibling worlds: Simplecooked (overcooked2_env, what the reference's trainers use) on its
+    # `simple` layout at the 32768-world shard, the balance beam at 1 M worlds
+    from madrona_rl_envs_playground_amd.simulators import BalanceBeamSimulator, SimplecookedSimulator
+    params = layouts.get_simplecooked_layout_params("simple", args.horizon)
+    n = args.worlds
+    sim = SimplecookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n, **params)
+    pool = [torch.randint(0, 6, (params["num_players"], n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(8)]
+    for i in range(20):
+        sim.step_with_actions(pool[i % 8])
+    us = launches_us(lambda i: sim.step_with_actions(pool[i % 8]), launches)
+    out[f"simplecooked_simple_{n}"] = leg(sim, n, us, f"simplecooked simple {n}")
+    sim.close()
+    n = 1 << 20
+    sim = BalanceBeamSimulator(exec_mode=ExecMode.CUDA, gpu_id=local_rank, num_worlds=n)
+    pool = [torch.randint(0, 4, (2, n, 1), dtype=torch.int32, device="cuda", generator=gen) for _ in range(8)]
+    for i in range(20):
+        sim.step_with_actions(pool[i % 8])
+    us = launches_us(lambda i: sim.step_with_actions(pool[i % 8]), launches)
+    out[f"balance_beam_{n}"] = leg(sim, n, us, f"balance_beam {n}")
+    sim.close()
+    del pool
 
     # configs[2]: Hanabi full game, 65536 worlds.  The reference harness draws argmax(rand * mask) with torch ops between
     # the steps (scripts/hanabi_example.py:64-67): `harness_loop_us_per_step` is that loop; `kernel_us_avg` is the step

@@ -191,13 +191,15 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["roofline"]["bound"] == "hbm" and out["cpu_baseline"]["kind"] == "port"
     legs = out["other_configs"]
-    want = [f"overcooked_{name}_32768" for name in STANDARD[1:]] + ["cartpole_1024", "cartpole_1048576", "hanabi_65536"]
+    want = ([f"overcooked_{name}_32768" for name in STANDARD[1:]] + ["cartpole_1024", "cartpole_1048576", "hanabi_65536"] +
+            ["simplecooked_simple_32768", "balance_beam_1048576"])  # (the two sibling worlds of SURVEY section 8(f)-4)
     assert sorted(legs) == sorted(want)
     for name, leg in legs.items():
         assert leg["launches_timed"] >= 300 and leg["kernel_us_avg"] > 0 and leg["value"] > 0 and leg["kernel"].startswith("mrl_"), name
         assert abs(leg["frac"] - leg["bytes_per_world_step"] * leg["worlds"] / (leg["kernel_us_avg"] * 1e-6) / 8e12) < 1e-9
     assert legs["hanabi_65536"]["kernel"] == "mrl_hanabi_step_fused" and legs["hanabi_65536"]["bytes_per_world_step"] == 1243
     assert legs["hanabi_65536"]["harness_loop_us_per_step"] > legs["hanabi_65536"]["kernel_us_avg"]
+    assert legs["hanabi_65536"]["rollout_kernel"] == "mrl_hanabi_rollout" and legs["hanabi_65536"]["persistent_rollout_us_per_step"] < legs["hanabi_65536"]["kernel_us_avg"]
     # traffic: only ever from this build's PMC passes
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "step_traffic.json")))

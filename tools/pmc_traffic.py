@@ -29,6 +29,8 @@ WORKLOADS = [  # (workload name as bench.py spells it, prof_step.py arguments)
     ("overcooked counter_circuit 32768", ["--game", "overcooked", "--layout", "counter_circuit", "--worlds", "32768"]),
     ("hanabi 65536", ["--game", "hanabi", "--worlds", "65536"]),
     ("cartpole 1048576", ["--game", "cartpole", "--worlds", "1048576"]),
+    ("simplecooked simple 32768", ["--game", "simplecooked", "--worlds", "32768"]),
+    ("balance_beam 1048576", ["--game", "balance", "--worlds", "1048576"]),
 ]
 
 
