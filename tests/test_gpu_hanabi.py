@@ -139,6 +139,27 @@ def test_full_game_encoder_matches_generic_encoder(hip_lib):
     slow.close()
 
 
+def test_persistent_rollout_in_all_three_code_variants(hip_lib):
+    """The full game through mrl_hanabi_rollout<2> (specialised encoders), <1> (five ranks) and <0> (any configuration): the same
+    seed leaves the same tensors after 150 steps in one launch each (the pipeline of phase-A / phase-B / scan waves is one
+    template, its phase A differs)."""
+    n, sims = 20000, []
+    for variant in (2, 1, 0):
+        with debug_knobs({"hanabi.variant": variant}):
+            sims.append(make(FULL, n))
+    assert all(s.rollout_kernel_name == "mrl_hanabi_rollout" for s in sims)
+    for s in sims:
+        s.rollout_random(150, seed=77, first_step=0)
+    names = ["observation_tensor", "agent_state_tensor", "action_mask_tensor", "active_agent_tensor", "reward_tensor", "done_tensor",
+             "game_tensor", "reset_count_tensor", "action_tensor"]
+    for other in sims[1:]:
+        for name in names:
+            assert torch.equal(getattr(sims[0], name)().to_torch(), getattr(other, name)().to_torch()), name
+    assert int(sims[0].reset_count_tensor().to_torch().item()) >= 0 and all(int(s.scan_timeout_tensor().to_torch().item()) == 0 for s in sims)
+    for s in sims:
+        s.close()
+
+
 @pytest.mark.parametrize("cfg,n,steps,heal", [(FULL, 5000, 80, 0), (FULL, 70001, 40, 0), (SMALL, 3000, 60, 0), (FULL, 70001, 60, 3),
                                               (FULL, 9000, 80, 1), (VERY_SMALL, 3000, 60, 2)],
                          ids=["full", "full_70001", "small", "full_70001_late_workgroups", "full_9000_all_late", "very_small_late"])
