@@ -40,7 +40,7 @@ its kernel, average launch duration over >= 300 launches, algorithmic bytes per 
 
 `roofline.traffic` (and `traffic` of the other legs) are HBM bytes per launch from rocprofv3 PMC passes, which
 cannot run inside this process: they come from profiles/step_traffic.json and are quoted only when that file's
-`csrc_sha16` equals the hash of the sources this library was built from (`_lib.source_hash()`), null otherwise.
+`csrc_sha16` equals the hash compiled into the running library (`mrl_build_hash()`, also on the line as `build_hash`), null otherwise.
 """
 import argparse
 import json
@@ -137,7 +137,7 @@ def measured_traffic(kernel, workload):
     from madrona_rl_envs_playground_amd import _lib
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "step_traffic.json")))
-        if pmc["csrc_sha16"] != _lib.source_hash():
+        if pmc["csrc_sha16"] != _lib.build_hash():
             return None
         for row in pmc["launches"]:
             if row["kernel"] == kernel and row["workload"] == workload:

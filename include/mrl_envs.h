@@ -419,7 +419,7 @@ void mrl_destroy(mrl_sim *sim);
  * overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.share_max_players, overcooked.share_private,
  * overcooked.no_share, overcooked.lds_pad, overcooked.no_fixed, overcooked.no_direct, overcooked.whole_store,
  * overcooked.store_policy, overcooked.wide_rollout, overcooked.groups, overcooked.shared_consts, overcooked.variant,
- * hanabi.variant, hanabi.pairing, hanabi.no_persistent, cartpole.no_persistent, fused_step (0 the library's choice, 1 one launch,
+ * hanabi.variant, hanabi.pairing, hanabi.no_persistent, cartpole.no_persistent, cartpole.variant, fused_step (0 the library's choice, 1 one launch,
  * 2 two launches), fused_heal_test, inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of
  * them.  Unknown key: MRL_ERR_INVALID.  No reference counterpart (the reference has MADRONA_* environment variables for its
  * JIT cache only). */
@@ -434,6 +434,11 @@ int mrl_probe_stream(void *dst_dev, const void *src_dev, uint64_t bytes, int mod
 /* message of the last failing call on this thread ("" if none) */
 const char *mrl_last_error(void);
 int mrl_abi_version(void);
+/* Which sources this binary was built from: the first 16 hex digits of a sha256 over the .hip and .hpp files of csrc/, its
+ * Makefile and this header (the Makefile computes it and compiles it in; the Python binding computes the same value from the files
+ * lying beside the library and refuses a library whose hash differs).  Measurements that cannot be taken inside a benchmark
+ * run (PMC traffic, profiles/step_traffic.json) are keyed by it.  No reference counterpart. */
+const char *mrl_build_hash(void);
 
 #ifdef __cplusplus
 }

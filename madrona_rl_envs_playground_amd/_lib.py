@@ -31,6 +31,7 @@ SYMBOLS = [
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
     "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
     "mrl_step_phase2_gathered", "mrl_set_observation_output", "mrl_set_observation_ring", "mrl_prepare_graph_capture", "mrl_step_many",
+    "mrl_build_hash",
 ]
 ABI_VERSION = 3  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
@@ -60,23 +61,29 @@ class MrlError(RuntimeError):
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip into libmrl_envs.so for gfx950 (needs hipcc, no GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+    """Compile csrc/*.hip into libmrl_envs.so for gfx950 (needs hipcc, no GPU).  Up to date means: the hash compiled into
+    the library (``mrl_build_hash``) is the hash of the sources lying beside it -- not file times."""
+    if not force and embedded_hash(LIB_PATH) == source_hash():
         return LIB_PATH
     jobs = str(min(6, os.cpu_count() or 1))  # one object per kernel file (csrc/Makefile)
     proc = subprocess.run(["make", "-C", CSRC, "-j", jobs] + (["-B"] if force else []), capture_output=True, text=True)
+    if proc.returncode == 0 and embedded_hash(LIB_PATH) != source_hash():
+        # file times said "up to date" but the binary is of other sources (a stale copy with a newer time): everything again
+        proc = subprocess.run(["make", "-C", CSRC, "-j", jobs, "-B"], capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout + proc.stderr)
     if proc.returncode != 0:
         raise MrlError("building libmrl_envs.so failed:\n" + proc.stdout + proc.stderr)
+    if embedded_hash(LIB_PATH) != source_hash():
+        raise MrlError(f"{LIB_PATH} was rebuilt but carries hash {embedded_hash(LIB_PATH)}, the sources hash to {source_hash()}")
     return LIB_PATH
 
 
 def source_hash():
-    """sha256 (first 16 hex digits) over the sources libmrl_envs.so is built from: csrc/*.hip, *.hpp, the Makefile and
-    include/mrl_envs.h.  Measurements that cannot be taken inside a benchmark run (PMC counters: profiles/step_traffic.json)
-    carry it, and are only quoted for the build they were taken on."""
+    """sha256 (first 16 hex digits) over the sources libmrl_envs.so is built from: name NUL contents of csrc/*.hip, *.hpp and
+    the Makefile in sorted order, then include/mrl_envs.h -- the value csrc/Makefile compiles into the library
+    (``mrl_build_hash()``).  Measurements that cannot be taken inside a benchmark run (PMC counters:
+    profiles/step_traffic.json) carry the LIBRARY's hash, and are only quoted for the build they were taken on."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")) or f == "Makefile")
@@ -84,6 +91,27 @@ def source_hash():
         h.update(os.path.basename(path).encode() + b"\0")
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
+
+
+_HASH_TAG = b"MRL_SOURCE_HASH="
+
+
+def embedded_hash(path):
+    """The source hash compiled into a library file, read from its bytes without loading it (None: no such file or no tag)."""
+    try:
+        blob = open(path, "rb").read()
+    except OSError:
+        return None
+    at = blob.find(_HASH_TAG)
+    if at < 0:
+        return None
+    value = blob[at + len(_HASH_TAG):at + len(_HASH_TAG) + 16]
+    return value.decode() if len(value) == 16 and all(c in b"0123456789abcdef" for c in value) else None
+
+
+def build_hash():
+    """``mrl_build_hash()`` of the loaded library."""
+    return lib().mrl_build_hash().decode()
 
 
 _lib = None
@@ -97,6 +125,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise MrlError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the step kernels.")
+    if os.path.isdir(CSRC) and embedded_hash(LIB_PATH) != source_hash():
+        # the binary must prove which sources it was built from: rebuild (hipcc cross-compiles anywhere) or refuse
+        stale = embedded_hash(LIB_PATH)
+        try:
+            build()
+        except (MrlError, OSError) as exc:
+            raise MrlError(f"{LIB_PATH} was built from other sources than those beside it (library {stale}, sources "
+                           f"{source_hash()}) and could not be rebuilt: {exc}") from None
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
     L.mrl_overcooked_create.argtypes = [ctypes.POINTER(OvercookedConfig), i32, u32, ctypes.POINTER(vp)]
@@ -133,12 +169,15 @@ def lib():
     L.mrl_destroy.restype = None
     L.mrl_last_error.restype = ctypes.c_char_p
     L.mrl_abi_version.restype = i32
+    L.mrl_build_hash.restype = ctypes.c_char_p
     L.mrl_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     L.mrl_probe_stream.argtypes = [vp, vp, ctypes.c_uint64, i32, i32, vp]
     L.mrl_scan_timed_out.argtypes = [vp]
     if L.mrl_abi_version() != ABI_VERSION:
         raise MrlError(f"{LIB_PATH} implements ABI version {L.mrl_abi_version()}, this binding expects {ABI_VERSION}: "
                        "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+    if os.path.isdir(CSRC) and L.mrl_build_hash().decode() != source_hash():
+        raise MrlError(f"{LIB_PATH} reports build hash {L.mrl_build_hash().decode()}, the sources beside it hash to {source_hash()}")
     _lib = L
     return L
 

@@ -35,6 +35,9 @@ static const char *const kDebugKeys[] = {
                              // 64 lanes, 1 the pairs are (2k, 2k + 1), 0 every wave steps its own 32 worlds
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
+    "cartpole.variant",      // arithmetic of the transition: 0 the library's default, 1 typed and rounded as the reference writes it (four double
+                             // divisions), 2 the same float roundings around fused double intermediates and reciprocals, 3 = 2 with sin/cos
+                             // evaluated without range reduction while |theta| <= pi/4 (the default), 4 float throughout (csrc/cartpole.hip)
     "fused_step",            // mrl_step of Hanabi / Cartpole as ONE launch with the in-kernel look-back (episode_scan.hpp) or as
                              // phase 1 + phase 2 launches: 0 the library's choice, 1 one launch where the kernel exists, 2 always two
     "fused_heal_test",       // m > 0: in the single-launch step, workgroups whose index is a multiple of m act as if dispatched late, so
@@ -180,6 +183,13 @@ using mrl::guarded;
 extern "C" {
 
 int mrl_abi_version(void) { return MRL_ABI_VERSION; }
+
+#ifndef MRL_SOURCE_HASH
+#error "build through csrc/Makefile: it passes -DMRL_SOURCE_HASH (the hash of the sources, see the Makefile)"
+#endif
+// "MRL_SOURCE_HASH=" in front so that the value can also be found in the file without loading it (_lib.embedded_hash)
+static const char g_build_hash[] = "MRL_SOURCE_HASH=" MRL_SOURCE_HASH;
+const char *mrl_build_hash(void) { return g_build_hash + sizeof("MRL_SOURCE_HASH=") - 1; }
 const char *mrl_last_error(void) { return mrl::g_error; }
 
 int mrl_overcooked_create(const mrl_overcooked_config *cfg, int gpu_id, uint32_t num_worlds, mrl_sim **out)

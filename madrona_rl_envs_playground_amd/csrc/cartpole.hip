@@ -21,6 +21,7 @@
 #include "random_policy.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -89,25 +90,120 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint
     return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
 }
 
-// sim.cpp:68-96 for one world; returns the done flag
-__device__ __forceinline__ bool advance(float4 &s, int32_t action)
+// ---- the transition (sim.cpp:68-96), in four arithmetic variants (mrl_debug_set "cartpole.variant") ----
+// The reference mixes float state with double literals, so nearly every intermediate is a double and the three
+// quotients by TOTAL_MASS plus the one by the pole term are four IEEE double divisions (v_div_scale x2 / v_rcp /
+// 7 fma / v_div_fmas / v_div_fixup each) -- ~85 double-precision instructions per world, and the step was bound by issuing
+// them.  What the contract asks is 1e-5 on identical actions (BASELINE.json), the reference's own check 1e-6
+// against a float64 numpy twin whose sin/cos are not sinf/cosf either (envs/cartpole_env.py:177-233,277).
+//   kRefTyped   every expression typed and rounded as sim.cpp writes it (rounds 1-3)
+//   kLean       the same float roundings (temp, costheta*temp, thetaacc, xacc and the four state components are rounded
+//               to float exactly where the reference rounds them) around double intermediates that are computed with
+//               fused multiply-adds, the constant quotients as products with the rounded reciprocal, and the one real
+//               quotient as v_rcp_f64 + one Newton step + one residual correction.  A double intermediate differs from the
+//               reference's by a few units in ITS last place, which survives the rounding to float with probability
+//               ~2^-20 per world-step and is then one float ulp.
+//   kLeanBounded  kLean, with sinf/cosf evaluated without range reduction while |theta| <= pi/4 (a live pole is within
+//               12 degrees; the library call, which carries a Payne-Hanek path, remains for anything else)
+//   kFloat      float throughout (fused multiply-adds, v_rcp_f32 + residual correction), bounded sin/cos
+enum Variant : int { kRefTyped = 0, kLean = 1, kLeanBounded = 2, kFloat = 3, kNumVariants = 4 };
+constexpr int kDefaultVariant = kLeanBounded;
+
+// sin and cos of one float: minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels, < 1 ulp there)
+__device__ __forceinline__ void sincos_bounded(float x, float *s, float *c)
+{
+    if (fabsf(x) <= 0.78539816f) {  // per lane: a world's result never depends on its neighbours in the wave
+        const float z = x * x;
+        float p = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+        p = __builtin_fmaf(p, z, -1.6666654611e-1f);
+        *s = __builtin_fmaf(p * z, x, x);
+        float q = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+        q = __builtin_fmaf(q, z, 4.166664568298827e-2f);
+        *c = __builtin_fmaf(q * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    } else {
+        sincosf(x, s, c);
+    }
+}
+
+// termination (sim.cpp:88-91 compares the float state with double literals): for a float v, v > T (double) is
+// v > largest float <= T, and v < -T likewise, so two float compares of |v| decide it (NaN: false on both sides, as there)
+__device__ __forceinline__ bool out_of_bounds(float x, float theta)
+{
+    constexpr float kXLimit = 0x1.333332p+1f;      // largest float <= 2.4 (2.4f itself rounds up)
+    constexpr float kThetaLimit = 0x1.acee9ep-3f;  // largest float <= 12 * 2 pi / 360
+    static_assert((double)kXLimit <= X_THRESHOLD && (double)kThetaLimit <= THETA_THRESHOLD, "limits must round down");
+    static_assert((double)(kXLimit + 0x1p-22f) > X_THRESHOLD && (double)(kThetaLimit + 0x1p-26f) > THETA_THRESHOLD, "and be the nearest such floats");
+    return fabsf(x) > kXLimit || fabsf(theta) > kThetaLimit;
+}
+
+template <int V> __device__ __forceinline__ bool advance(float4 &s, int32_t action)
 {
     float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
-    // expression types as written in sim.cpp:70-83
-    const float force = (action == 1 ? FORCE_MAG : -FORCE_MAG);
-    float sintheta, costheta;
-    sincosf(theta, &sintheta, &costheta);  // one range reduction for both (sim.cpp:71-72 calls cosf and sinf)
-    const float temp = (force + POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / TOTAL_MASS;
-    const float thetaacc =
-        (GRAVITY * sintheta - costheta * temp) / (LENGTH * (4.0 / 3.0 - MASSPOLE * costheta * costheta / TOTAL_MASS));
-    const float xacc = temp - POLEMASS_LENGTH * thetaacc * costheta / TOTAL_MASS;
-    x = x + TAU * x_dot;
-    x_dot = x_dot + TAU * xacc;
-    theta = theta + TAU * theta_dot;
-    theta_dot = theta_dot + TAU * thetaacc;
-    s = make_float4(x, x_dot, theta, theta_dot);
-    // sim.cpp:88-91
-    return x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
+    if constexpr (V == kRefTyped) {
+        // expression types as written in sim.cpp:70-83
+        const float force = (action == 1 ? FORCE_MAG : -FORCE_MAG);
+        float sintheta, costheta;
+        sincosf(theta, &sintheta, &costheta);  // one range reduction for both (sim.cpp:71-72 calls cosf and sinf)
+        const float temp = (force + POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / TOTAL_MASS;
+        const float thetaacc =
+            (GRAVITY * sintheta - costheta * temp) / (LENGTH * (4.0 / 3.0 - MASSPOLE * costheta * costheta / TOTAL_MASS));
+        const float xacc = temp - POLEMASS_LENGTH * thetaacc * costheta / TOTAL_MASS;
+        x = x + TAU * x_dot;
+        x_dot = x_dot + TAU * xacc;
+        theta = theta + TAU * theta_dot;
+        theta_dot = theta_dot + TAU * thetaacc;
+        s = make_float4(x, x_dot, theta, theta_dot);
+        // sim.cpp:88-91
+        return x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
+    } else if constexpr (V == kLean || V == kLeanBounded) {
+        constexpr double kInvMass = 1.0 / TOTAL_MASS;                            // 1 / 1.1
+        constexpr double kPoleOverMass = POLEMASS_LENGTH / TOTAL_MASS;           // 0.05 / 1.1
+        constexpr double kFourThirdsLength = LENGTH * 4.0 / 3.0;                 // 0.5 * 4/3
+        float sintheta, costheta;
+        if constexpr (V == kLeanBounded) sincos_bounded(theta, &sintheta, &costheta);
+        else sincosf(theta, &sintheta, &costheta);
+        const double sn = sintheta, cs = costheta, td = theta_dot;
+        const double force = action == 1 ? (double)FORCE_MAG : -(double)FORCE_MAG;
+        const float temp = (float)(__builtin_fma((POLEMASS_LENGTH * td) * td, sn, force) * kInvMass);
+        const float ct = costheta * temp;  // float * float in the reference too
+        const double num = __builtin_fma(GRAVITY, sn, -(double)ct);
+        const double den = __builtin_fma(-kPoleOverMass, cs * cs, kFourThirdsLength);  // in [0.62, 0.67]
+        double r = __builtin_amdgcn_rcp(den);               // ~2^-23
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);  // ~2^-46
+        double q = num * r;
+        q = __builtin_fma(__builtin_fma(-den, q, num), r, q);  // residual correction: a unit or two in the last place
+        const float thetaacc = (float)q;
+        const double ta = thetaacc;
+        const float xacc = (float)__builtin_fma(-kPoleOverMass * ta, cs, (double)temp);
+        const double xd = x_dot;
+        x = (float)__builtin_fma(TAU, xd, (double)x);
+        x_dot = (float)__builtin_fma(TAU, (double)xacc, xd);
+        theta = (float)__builtin_fma(TAU, td, (double)theta);
+        theta_dot = (float)__builtin_fma(TAU, ta, td);
+        s = make_float4(x, x_dot, theta, theta_dot);
+        return out_of_bounds(x, theta);
+    } else {
+        constexpr float kInvMass = (float)(1.0 / TOTAL_MASS);
+        constexpr float kPoleOverMass = (float)(POLEMASS_LENGTH / TOTAL_MASS);
+        constexpr float kFourThirdsLength = (float)(LENGTH * 4.0 / 3.0);
+        float sintheta, costheta;
+        sincos_bounded(theta, &sintheta, &costheta);
+        const float force = action == 1 ? (float)FORCE_MAG : -(float)FORCE_MAG;
+        const float temp = __builtin_fmaf(((float)POLEMASS_LENGTH * theta_dot) * theta_dot, sintheta, force) * kInvMass;
+        const float num = __builtin_fmaf((float)GRAVITY, sintheta, -(costheta * temp));
+        const float den = __builtin_fmaf(-kPoleOverMass, costheta * costheta, kFourThirdsLength);
+        const float r = __builtin_amdgcn_rcpf(den);
+        float q = num * r;
+        q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+        const float thetaacc = q;
+        const float xacc = __builtin_fmaf(-kPoleOverMass * thetaacc, costheta, temp);
+        const float nx = __builtin_fmaf((float)TAU, x_dot, x);
+        const float nxd = __builtin_fmaf((float)TAU, xacc, x_dot);
+        const float nt = __builtin_fmaf((float)TAU, theta_dot, theta);
+        const float ntd = __builtin_fmaf((float)TAU, thetaacc, theta_dot);
+        s = make_float4(nx, nxd, nt, ntd);
+        return out_of_bounds(nx, nt);
+    }
 }
 
 constexpr int kUnroll = 4;  // worlds per thread whose loads are in flight together
@@ -121,6 +217,7 @@ constexpr int kUnroll = 4;  // worlds per thread whose loads are in flight toget
 // flags as one word of `finished_mask` (world i is bit i % 64 of word i / 64; a wave's worlds are
 // 64-aligned because chunk and kBlock are multiples of 64).  The reset launch reads those words
 // -- 128 bytes per 1024 worlds instead of 4 KB of flags -- and ranks the set bits with popcounts.
+template <int V>
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t chunk, const int32_t *__restrict__ action,
                                                             float4 *__restrict__ state, float *__restrict__ reward,
                                                             int32_t *__restrict__ done, uint32_t *__restrict__ block_counts,
@@ -144,7 +241,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t
             const uint32_t i = i0 + u * kBlock;
             bool over = false;
             if (i < last) {
-                over = advance(s[u], a[u]);
+                over = advance<V>(s[u], a[u]);
                 state[i] = s[u];
                 reward[i] = 1.f;
                 done[i] = over ? 1 : 0;
@@ -232,6 +329,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
 // How many of workgroup j's worlds finish in this step, worked out by ONE wave of another workgroup from j's inputs in
 // HBM: what the healing look-back of the single-launch step calls for a workgroup whose own count has not appeared
 // (episode_scan.hpp).  Inlined: a call would give the kernel a stack in scratch memory.  It never runs on an idle GPU.
+template <int V>
 __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *action, const float4 *state, uint32_t j,
                                                              bool sampled, uint64_t sample_seed, uint32_t sample_step)
 {
@@ -243,7 +341,7 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
         const uint32_t i = i0 + lane, ic = i < last ? i : first;
         float4 s = state[ic];
         const int32_t a = sampled ? (int32_t)(mrl::policy_hash(sample_seed, sample_step, ic, 0) >> 31) : action[ic];
-        const bool over = i < last && advance(s, a);
+        const bool over = i < last && advance<V>(s, a);
         count += (uint32_t)__popcll(__ballot(over));
     }
     return count;
@@ -257,6 +355,7 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
 // the two-launch pair above stays for the sharded path, whose episode base comes from the other
 // ranks between the phases.  A workgroup stores its worlds' state only after its count is globally
 // visible (the publishing wave waits for its store before the barrier everybody passes).
+template <int V>
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
                                                                   int32_t *__restrict__ done, unsigned long long *status,
@@ -298,7 +397,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
-        over[u] = i < last && advance(s[u], a[u]);
+        over[u] = i < last && advance<V>(s[u], a[u]);
         votes[u] = __ballot(over[u]);
         if (lane == 0) s_votes[u][wave] = (uint32_t)__popcll(votes[u]);
     }
@@ -325,7 +424,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     if (wave == 0 && (block_total != 0 || last_block)) {
         const bool sampled = action_out != nullptr;
         const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
-            return recount_chunk(n, action, state, j, sampled, sample_seed, sample_step);
+            return recount_chunk<V>(n, action, state, j, sampled, sample_seed, sample_step);
         });
         if (lane == 0) s_prefix = before;
     }
@@ -361,6 +460,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
 // one launch per step; waits are bounded (SCAN_TIMEOUT).
 constexpr int kRing = 4;
 
+template <int V>
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float4 *__restrict__ state, float *__restrict__ reward,
                                                                int32_t *__restrict__ done, int32_t *__restrict__ action_out,
                                                                unsigned long long *ring, uint32_t epoch0, uint32_t num_steps,
@@ -391,7 +491,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t i = first + u * kBlock + threadIdx.x;
             const int32_t a = (int32_t)(mrl::policy_hash(seed, first_step + k, i < last ? i : first, 0) >> 31);
-            over[u] = i < last && advance(s[u], a);
+            over[u] = i < last && advance<V>(s[u], a);
             finished += over[u] ? 1u : 0u;
             if (i < last) {
                 action_out[i] = a;
@@ -478,8 +578,20 @@ __global__ void mrl_cartpole_init(uint32_t n, uint32_t world_offset, float4 *sta
     }
 }
 
+// runs f(std::integral_constant<int, V>) for the arithmetic variant picked at creation
+template <typename F> void with_variant(int variant, F &&f)
+{
+    switch (variant) {
+    case kRefTyped: f(std::integral_constant<int, kRefTyped>{}); break;
+    case kLean: f(std::integral_constant<int, kLean>{}); break;
+    case kFloat: f(std::integral_constant<int, kFloat>{}); break;
+    default: f(std::integral_constant<int, kLeanBounded>{}); break;
+    }
+}
+
 struct CartpoleSim final : mrl_sim {
     uint32_t grid = 0;
+    int variant = kDefaultVariant;  // arithmetic of the transition (mrl_debug_set cartpole.variant: 1 + Variant; 0 = the default)
     int32_t *action = nullptr, *done = nullptr, *world_id = nullptr;
     float4 *state = nullptr;
     float *reward = nullptr;
@@ -515,9 +627,11 @@ struct CartpoleSim final : mrl_sim {
     {
         epoch += 1;
         if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
-        hipLaunchKernelGGL(mrl_cartpole_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions, state,
-                           reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed,
-                           sample_step, heal, launch_state.counter_args(counter));
+        with_variant(variant, [&](auto v) {
+            hipLaunchKernelGGL(mrl_cartpole_step_fused<decltype(v)::value>, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds,
+                               actions, state, reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count,
+                               action_out, seed, sample_step, heal, launch_state.counter_args(counter));
+        });
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -538,8 +652,11 @@ struct CartpoleSim final : mrl_sim {
             mrl::Alarm al = alarm.alarm();
             void *args[] = {&n, &state, &reward, &done, &action, &ring, &epoch0, &num_steps, &first_step, &seed, &base, &next,
                             &reset_count, &al};
-            const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_cartpole_rollout), dim3(fused_grid),
-                                                              dim3(kBlock), args, 0, stream);
+            hipError_t err = hipSuccess;
+            with_variant(variant, [&](auto v) {
+                err = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&mrl_cartpole_rollout<decltype(v)::value>),
+                                                 dim3(fused_grid), dim3(kBlock), args, 0, stream);
+            });
             if (err == hipSuccess) {
                 ring_epoch += num_steps;
                 parity ^= 1u;
@@ -561,8 +678,10 @@ struct CartpoleSim final : mrl_sim {
 
     void phase1(const int32_t *actions, hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl_cartpole_step, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk,
-                           actions ? actions : action, state, reward, done, block_counts, finished_mask);
+        with_variant(variant, [&](auto v) {
+            hipLaunchKernelGGL(mrl_cartpole_step<decltype(v)::value>, dim3(grid), dim3(kBlock), 0, stream, num_worlds, chunk,
+                               actions ? actions : action, state, reward, done, block_counts, finished_mask);
+        });
         MRL_HIP(hipGetLastError());
     }
 
@@ -646,6 +765,14 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         sim->device = gpu_id;
         sim->num_worlds = num_worlds;
         {
+            const int64_t knob = mrl::debug_get("cartpole.variant", 0);  // 0: the default; 1 + Variant otherwise
+            if (knob < 0 || knob > kNumVariants) {
+                mrl::set_error("cartpole.variant must be 0 (default) or 1..%d", (int)kNumVariants);
+                throw mrl::HipError{MRL_ERR_INVALID};
+            }
+            sim->variant = knob == 0 ? kDefaultVariant : (int)knob - 1;
+        }
+        {
             const uint32_t groups = (num_worlds + kBlock - 1) / kBlock;
             const uint32_t blocks = groups < mrl::kMaxScanBlocks ? groups : mrl::kMaxScanBlocks;
             sim->chunk = ((groups + blocks - 1) / blocks) * kBlock;
@@ -683,7 +810,10 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
         }
         if (sim->fused_grid) {
             int per_cu = 0, cus = 0;
-            MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&mrl_cartpole_rollout), kBlock, 0));
+            with_variant(sim->variant, [&](auto v) {
+                MRL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                    &per_cu, reinterpret_cast<const void *>(&mrl_cartpole_rollout<decltype(v)::value>), kBlock, 0));
+            });
             MRL_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
             // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
             // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)

@@ -99,3 +99,42 @@ def test_header_lists_every_debug_key():
     doc = header[header.index("Keys (with their meanings"):header.index("key == NULL forgets")]
     in_header = set(re.findall(r"\b((?:overcooked|hanabi|cartpole)\.[a-z_]+|fused_step|fused_heal_test|inject_scan_timeout|ablate|stamps)\b", doc))
     assert in_code == in_header and len(in_code) >= 20
+
+
+def test_library_proves_which_sources_it_was_built_from(hip_lib, tmp_path, monkeypatch):
+    """The hash of the sources is compiled into the library (csrc/Makefile -> mrl_build_hash()).  A library lying beside
+    sources it was not built from is refused -- or rebuilt, where hipcc is at hand -- whatever the file times say."""
+    import shutil
+    import subprocess
+    from madrona_rl_envs_playground_amd import _lib
+    assert hip_lib.mrl_build_hash().decode() == _lib.source_hash() == _lib.embedded_hash(_lib.LIB_PATH)
+    # a copy of the package's native part: sources, header, the built library
+    pkg = tmp_path / "pkg"
+    shutil.copytree(_lib.CSRC, pkg / "csrc", ignore=shutil.ignore_patterns("build", "build_diag"))
+    (tmp_path / "include").mkdir()
+    shutil.copy(_lib.HEADER, tmp_path / "include" / "mrl_envs.h")
+    shutil.copy(_lib.LIB_PATH, pkg / "libmrl_envs.so")
+    monkeypatch.setattr(_lib, "CSRC", str(pkg / "csrc"))
+    monkeypatch.setattr(_lib, "HEADER", str(tmp_path / "include" / "mrl_envs.h"))
+    monkeypatch.setattr(_lib, "LIB_PATH", str(pkg / "libmrl_envs.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.embedded_hash(_lib.LIB_PATH) == _lib.source_hash()           # the copy is consistent (not loaded: dlopen would keep it)
+    # one byte of one header changes; the library is given the newest file time of all
+    hpp = pkg / "csrc" / "random_policy.hpp"
+    text = hpp.read_bytes()
+    at = text.index(b"0x9E3779B9")
+    hpp.write_bytes(text[:at] + b"0x9E3779B1" + text[at + 10:])
+    os.utime(pkg / "libmrl_envs.so")
+    before = _lib.source_hash()
+    assert before != _lib.embedded_hash(_lib.LIB_PATH)
+    monkeypatch.setattr(_lib, "_lib", None)
+    real_run = subprocess.run
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no compiler here")))
+    with pytest.raises(_lib.MrlError, match="built from other sources"):
+        _lib.lib()
+    monkeypatch.setattr(subprocess, "run", real_run)
+    # with the compiler at hand the same call rebuilds -- make alone would have called the newer file up to date
+    L = _lib.lib()
+    assert L.mrl_build_hash().decode() == before == _lib.embedded_hash(_lib.LIB_PATH)
+    monkeypatch.undo()
+    assert _lib.lib().mrl_build_hash().decode() == _lib.source_hash()

@@ -75,6 +75,65 @@ def test_lockstep_vs_oracle(n, steps, hip_lib, oracle_lib):
     assert resets > 0
 
 
+VARIANTS = {1: "reference_typed", 2: "lean_f64", 3: "lean_f64_bounded_sincos", 4: "float"}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS), ids=[VARIANTS[v] for v in sorted(VARIANTS)])
+def test_arithmetic_variants(variant, hip_lib, oracle_lib):
+    """csrc/cartpole.hip evaluates the transition in one of four ways (mrl_debug_set cartpole.variant; 3 is the default).
+    Each must hold the reference's own one-step bound, 1e-6 against its float64 numpy twin (envs/cartpole_env.py:277), on
+    the reference-generated transitions, termination flags included (outside the band where a last-place difference
+    decides), and 1e-5 against the oracle in lock-step with bit-equal fresh states."""
+    import os
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cartpole_transitions.npz"))
+    states, actions, next64, done = z["states"], z["actions"], z["next64"], z["done"]
+    m = len(states)
+    with debug_knobs({"cartpole.variant": variant}):
+        g, sim = make(m), make(50000)
+    g.observation_tensor().to_torch().copy_(torch.from_numpy(states).cuda())
+    g.action_tensor().to_torch().copy_(torch.from_numpy(actions).cuda().view(m, 1))
+    g.step_phase1(None)
+    got = g.observation_tensor().to_torch().cpu().numpy().astype(np.float64)
+    got_done = g.reset_tensor().to_torch().cpu().numpy()[:, 0]
+    near = (np.abs(np.abs(next64[:, 0]) - 2.4) < 1e-5) | (np.abs(np.abs(next64[:, 2]) - 12 * 2 * np.pi / 360) < 1e-5)
+    assert ((got_done == done) | near).all()
+    assert np.abs(got - next64).max() < 1e-6, np.abs(got - next64).max()
+    g.close()
+    n = 50000
+    orc = oracle_lib.CartpoleOracle(n, num_threads=8)
+    st, act = sim.observation_tensor().to_torch(), sim.action_tensor().to_torch()
+    torch.manual_seed(variant)
+    worst, flips = 0.0, 0
+    for t in range(60):
+        a = torch.randint(0, 2, (n, 1), dtype=torch.int32)
+        orc.step(a.numpy())
+        act.copy_(a.cuda())
+        sim.step()
+        got = st.cpu().numpy()
+        done_gpu, done_cpu = sim.reset_tensor().to_torch().cpu().numpy()[:, 0], orc.done[:, 0]
+        agree = done_gpu == done_cpu
+        flips += int((~agree).sum())
+        keep = agree & (done_cpu == 0)
+        worst = max(worst, float(np.abs(got[keep] - orc.state[keep]).max()))
+        if agree.all() and done_cpu.any():
+            r = done_cpu == 1
+            assert np.array_equal(got[r].view(np.uint32), orc.state[r].view(np.uint32)), f"reset state, step {t}"
+        st.copy_(torch.from_numpy(orc.state).cuda())
+        if not agree.all():
+            sim.set_episode_counter(orc.episodes)
+    assert worst <= (1e-6 if variant != 4 else TOL), f"max |gpu - oracle| = {worst}"
+    assert flips <= 15, f"{flips} done flags disagree"
+    sim.close()
+
+
+def test_unknown_arithmetic_variant_is_refused(hip_lib):
+    from madrona_rl_envs_playground_amd._lib import MrlError, debug_knobs
+    with debug_knobs({"cartpole.variant": 9}):
+        with pytest.raises(MrlError, match="cartpole.variant"):
+            make(64)
+
+
 @pytest.mark.parametrize("n,pattern", [(300001, "all"), (300001, "dense_block"), (1 << 20, "sparse"), (777, "all")])
 def test_planted_terminations_take_episodes_in_world_order(n, pattern, hip_lib, oracle_lib):
     """The reset launch ranks a workgroup's short list of finished worlds in LDS and falls back to

@@ -205,7 +205,7 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
         pmc = json.load(open(os.path.join(REPO, "profiles", "step_traffic.json")))
     except OSError:
         pmc = None
-    same_build = pmc is not None and pmc["csrc_sha16"] == _lib.source_hash()
+    same_build = pmc is not None and pmc["csrc_sha16"] == _lib.build_hash()
     quoted = [out["roofline"]["traffic"]] + [leg["traffic"] for leg in legs.values()]
     if not same_build:
         assert all(t is None for t in quoted)

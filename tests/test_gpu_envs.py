@@ -135,7 +135,8 @@ def test_hanabi_env_wrapper(hip_lib):
 
 
 def test_cartpole_golden_transitions_on_gpu(hip_lib):
-    """One step from the reference-generated start states (tolerance of the north star: 1e-5)."""
+    """One step from the reference-generated start states: within the reference's own bound of 1e-6 against its float64
+    numpy twin (envs/cartpole_env.py:277; the north star asks 1e-5)."""
     z = np.load(os.path.join(GOLDEN, "cartpole_transitions.npz"))
     states, actions, next64, done = z["states"], z["actions"], z["next64"], z["done"]
     m = len(states)
@@ -147,7 +148,7 @@ def test_cartpole_golden_transitions_on_gpu(hip_lib):
     got, got_done = st.cpu().numpy().astype(np.float64), sim.reset_tensor().to_torch().cpu().numpy()[:, 0]
     near = (np.abs(np.abs(next64[:, 0]) - 2.4) < 1e-5) | (np.abs(np.abs(next64[:, 2]) - 12 * 2 * np.pi / 360) < 1e-5)
     assert ((got_done == done) | near).all()
-    assert np.abs(got - next64).max() < 1e-5
+    assert np.abs(got - next64).max() < 1e-6
     sim.close()
 
 

@@ -1,13 +1,16 @@
-"""GPU, BASELINE.json's full sizes: size-independent properties instead of a
-lock-step oracle (which would take minutes of CPU at these sizes), plus a
-sampled lock-step against the oracle on a slice of the batch."""
+"""GPU, BASELINE.json's full sizes.  Overcooked config 2: size-independent properties over all 32768 worlds plus a
+lock-step against the oracle on a slice of the batch.  Hanabi config 3 (65536 worlds) and the 1 M-world Cartpole batch:
+the WHOLE batch in lock-step against the multi-threaded C oracle (a few seconds of CPU per test), through the kernels
+mrl_step and mrl_rollout_random actually run at those sizes -- the single-launch step, whose look-back across all 256
+workgroups decides every episode number, and the persistent rollout -- and, beside them, the size-independent
+properties."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-from madrona_rl_envs_playground_amd import layouts  # noqa: E402
+from madrona_rl_envs_playground_amd import hanabi_spec, layouts  # noqa: E402
 from madrona_rl_envs_playground_amd.simulators import (CartpoleSimulator, ExecMode, HanabiSimulator,  # noqa: E402
                                                        OvercookedSimulator)
 
@@ -139,4 +142,137 @@ def test_cartpole_one_million_worlds(hip_lib):
         assert (st[:, 0].abs() <= 2.4 + 0.2).all() and torch.isfinite(st).all()
         assert int(sim.reset_count_tensor().to_torch().item()) == int(done.sum())
     assert resets > n  # random policy: ~20-step episodes
+    sim.close()
+
+
+HANABI_FULL = dict(colors=5, ranks=5, players=2, max_information_tokens=8, max_life_tokens=3)
+
+
+def _hanabi_equal(sim, orc, tag):
+    """Every exported tensor and the 176-byte game record of every world against the oracle (compared on the device: the
+    oracle's arrays go up, 190 MB per step, instead of the simulator's coming down)."""
+    no, ns = hanabi_spec.observation_size(HANABI_FULL), hanabi_spec.state_size(HANABI_FULL)
+
+    def same(name, got, want):
+        want = torch.from_numpy(np.ascontiguousarray(want)).cuda()
+        assert torch.equal(got.view(want.dtype) if got.dtype != want.dtype else got, want), f"{name} differs from the oracle, {tag}"
+
+    same("observation", sim.observation_tensor().to_torch()[..., :no], orc.obs[..., :no].view(np.int8))
+    same("state", sim.agent_state_tensor().to_torch()[..., :ns], orc.state[..., :ns].view(np.int8))
+    same("legal moves", sim.action_mask_tensor().to_torch(), orc.mask)
+    same("active", sim.active_agent_tensor().to_torch(), orc.active)
+    same("reward", sim.reward_tensor().to_torch(), orc.reward)
+    same("done", sim.done_tensor().to_torch(), orc.done)
+    same("game record", sim.game_tensor().to_torch(), orc.dump())
+
+
+def test_hanabi_65536_worlds_lockstep_vs_oracle(hip_lib, oracle_lib):
+    """configs[2] at its own size against the ORACLE: 40 masked-random steps (the reference harness's policy,
+    scripts/hanabi_example.py:64-67) through sim.step() -- one launch per step, episode numbers from the look-back over
+    all 256 workgroups (reference: one global atomic, src/hanabi_env/sim.cpp:446-451; done + inline reset :812-850)."""
+    import os
+    n = 65536
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **HANABI_FULL)
+    assert sim.kernel_name == "mrl_hanabi_step_fused" and sim.launch_shape[0] == 256
+    orc = oracle_lib.HanabiOracle(HANABI_FULL, n, num_threads=min(16, os.cpu_count() or 1))
+    _hanabi_equal(sim, orc, "initial")
+    rng = np.random.default_rng(65536)
+    act = sim.action_tensor().to_torch()
+    finished = 0
+    for t in range(40):
+        logits = rng.random(orc.mask.shape, dtype=np.float32) * (orc.mask != 0)
+        a = logits.argmax(-1).astype(np.int32)
+        orc.step(a)
+        act.copy_(torch.from_numpy(a).cuda().view(2, n, 1))
+        sim.step()
+        _hanabi_equal(sim, orc, f"step {t}")
+        finished += int(orc.done.sum())
+        assert int(sim.reset_count_tensor().to_torch().item()) == int(orc.done.sum())
+    assert finished > n // 2, "too few games ended for the episode numbering to matter"
+    assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
+    sim.close()
+
+
+def test_hanabi_65536_worlds_persistent_rollout_vs_oracle(hip_lib, oracle_lib):
+    """One mrl_rollout_random(K) -- the persistent cooperative launch, all K steps with the records in LDS -- replayed
+    through the oracle with the documented action stream (simulators.random_hanabi_action); then a second call continuing
+    the step count, and an ordinary step after it."""
+    import os
+    from madrona_rl_envs_playground_amd.simulators import random_hanabi_action
+    n, seed = 65536, 0x5EED0004
+    sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **HANABI_FULL)
+    orc = oracle_lib.HanabiOracle(HANABI_FULL, n, num_threads=min(16, os.cpu_count() or 1))
+    world = np.arange(n)
+
+    def replay(first, count):
+        last = None
+        for t in range(first, first + count):
+            mover = (orc.active[1] != 0).astype(np.int64)
+            want = random_hanabi_action(seed, t, world, mover, orc.mask[mover, world])
+            acts = np.zeros((2, n), np.int32)
+            acts[mover, world] = want
+            orc.step(acts)
+            last = (mover, want)
+        return last
+
+    assert sim.rollout_kernel_name == "mrl_hanabi_rollout"
+    sim.rollout_random(33, seed=seed, first_step=7)
+    mover, want = replay(7, 33)
+    _hanabi_equal(sim, orc, "after a 33-step persistent launch")
+    assert np.array_equal(sim.action_tensor().to_torch().cpu().numpy()[mover, world, 0], want)  # the last step's draws
+    sim.rollout_random(9, seed=seed, first_step=40)
+    replay(40, 9)
+    _hanabi_equal(sim, orc, "after a second launch of 9 steps")
+    assert sim.rollout_kernel_name == "mrl_hanabi_rollout", "the runtime refused the cooperative launch: these were launches per step"
+    rng = np.random.default_rng(3)
+    a = (rng.random(orc.mask.shape, dtype=np.float32) * (orc.mask != 0)).argmax(-1).astype(np.int32)
+    orc.step(a)
+    sim.action_tensor().to_torch().copy_(torch.from_numpy(a).cuda().view(2, n, 1))
+    sim.step()
+    _hanabi_equal(sim, orc, "an ordinary step after the rollouts")
+    assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
+    sim.close()
+
+
+@pytest.mark.parametrize("fused", [0, 1], ids=["library_choice", "single_launch"])
+def test_cartpole_one_million_worlds_lockstep_vs_oracle(fused, hip_lib, oracle_lib):
+    """1 048 576 worlds x 30 random-action steps against the oracle with the resync protocol of
+    tests/test_gpu_cartpole.py::test_lockstep_vs_oracle: one-step differential at 1e-5 (float state; the reference's own check
+    is one step too, envs/cartpole_env.py:246-288), fresh states of re-seeded worlds bit for bit -- 50 000 of them per step,
+    numbered across all 1024 workgroups (reference: src/cartpole_env/sim.cpp:48-66)."""
+    import os
+    from madrona_rl_envs_playground_amd._lib import debug_knobs
+    n = 1 << 20
+    with debug_knobs({"fused_step": fused}):
+        sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
+    assert sim.kernel_name == ("mrl_cartpole_step_fused" if fused else "mrl_cartpole_step")
+    orc = oracle_lib.CartpoleOracle(n, num_threads=min(16, os.cpu_count() or 1))
+    st, act = sim.observation_tensor().to_torch(), sim.action_tensor().to_torch()
+    assert np.array_equal(st.cpu().numpy().view(np.uint32), orc.state.view(np.uint32)), "initial states"
+    torch.manual_seed(0)
+    worst, flips, resets, exact_steps = 0.0, 0, 0, 0
+    for t in range(30):
+        a = torch.randint(0, 2, (n, 1), dtype=torch.int32)
+        orc.step(a.numpy())
+        act.copy_(a.cuda())
+        sim.step()
+        got = st.cpu().numpy()
+        done_gpu, done_cpu = sim.reset_tensor().to_torch().cpu().numpy()[:, 0], orc.done[:, 0]
+        agree = done_gpu == done_cpu
+        flips += int((~agree).sum())
+        keep = agree & (done_cpu == 0)
+        worst = max(worst, float(np.abs(got[keep] - orc.state[keep]).max()))
+        if agree.all():  # then every finished world must have taken the oracle's episode number
+            r = done_cpu == 1
+            resets += int(r.sum())
+            exact_steps += 1
+            assert np.array_equal(got[r].view(np.uint32), orc.state[r].view(np.uint32)), f"fresh states, step {t}"
+            assert int(sim.reset_count_tensor().to_torch().item()) == int(r.sum())
+        st.copy_(torch.from_numpy(orc.state).cuda())
+        if not agree.all():
+            sim.set_episode_counter(orc.episodes)
+    assert worst <= 1e-5, f"max |gpu - oracle| over non-terminal worlds = {worst}"
+    assert flips <= 30 * n // 200000, f"{flips} done flags disagree"
+    assert exact_steps >= 15 and resets > n // 2, (exact_steps, resets)
+    assert int(sim.scan_timeout_tensor().to_torch().item()) == 0
     sim.close()
