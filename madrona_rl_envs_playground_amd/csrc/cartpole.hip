@@ -26,7 +26,6 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kFusedStepMaxWorlds = 4096;  // mrl_step as one launch up to here, as two above (see create_cartpole)
 
 #define GRAVITY 9.8
 #define MASSCART 1.0
@@ -109,20 +108,19 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint
 enum Variant : int { kRefTyped = 0, kLean = 1, kLeanBounded = 2, kFloat = 3, kNumVariants = 4 };
 constexpr int kDefaultVariant = kLeanBounded;
 
-// sin and cos of one float: minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels, < 1 ulp there)
-__device__ __forceinline__ void sincos_bounded(float x, float *s, float *c)
+// sin and cos of one float by minimax polynomials on [-pi/4, pi/4] (the classic single-precision kernels, < 1 ulp there);
+// outside that range the caller takes the library's sincosf.  The choice is per world: a world's result never depends on
+// its neighbours in the wave or in the thread.
+constexpr float kQuarterPi = 0.78539816f;
+__device__ __forceinline__ void sincos_poly(float x, float *s, float *c)
 {
-    if (fabsf(x) <= 0.78539816f) {  // per lane: a world's result never depends on its neighbours in the wave
-        const float z = x * x;
-        float p = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-        p = __builtin_fmaf(p, z, -1.6666654611e-1f);
-        *s = __builtin_fmaf(p * z, x, x);
-        float q = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-        q = __builtin_fmaf(q, z, 4.166664568298827e-2f);
-        *c = __builtin_fmaf(q * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-    } else {
-        sincosf(x, s, c);
-    }
+    const float z = x * x;
+    float p = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = __builtin_fmaf(p, z, -1.6666654611e-1f);
+    *s = __builtin_fmaf(p * z, x, x);
+    float q = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    q = __builtin_fmaf(q, z, 4.166664568298827e-2f);
+    *c = __builtin_fmaf(q * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
 }
 
 // termination (sim.cpp:88-91 compares the float state with double literals): for a float v, v > T (double) is
@@ -136,32 +134,45 @@ __device__ __forceinline__ bool out_of_bounds(float x, float theta)
     return fabsf(x) > kXLimit || fabsf(theta) > kThetaLimit;
 }
 
-template <int V> __device__ __forceinline__ bool advance(float4 &s, int32_t action)
+// The transition in two halves.  The new cart position and pole angle -- and with them the termination flag -- depend on
+// the OLD velocities only (explicit Euler, sim.cpp:79,81,88-91): two multiply-adds per world.  The single-launch step works
+// that half out first, publishes its workgroup's count of finished worlds, and runs the expensive half (sin, cos, the
+// accelerations) while the count travels and the look-back reads the other workgroups' (mrl_cartpole_step_fused).
+template <int V> __device__ __forceinline__ bool next_pose(const float4 &s, float &x, float &theta)
 {
-    float x = s.x, x_dot = s.y, theta = s.z, theta_dot = s.w;
+    if constexpr (V == kRefTyped) {
+        x = s.x + TAU * s.y;
+        theta = s.z + TAU * s.w;
+        return x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;  // sim.cpp:88-91
+    } else if constexpr (V == kLean || V == kLeanBounded) {
+        x = (float)__builtin_fma(TAU, (double)s.y, (double)s.x);
+        theta = (float)__builtin_fma(TAU, (double)s.w, (double)s.z);
+        return out_of_bounds(x, theta);
+    } else {
+        x = __builtin_fmaf((float)TAU, s.y, s.x);
+        theta = __builtin_fmaf((float)TAU, s.w, s.z);
+        return out_of_bounds(x, theta);
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void rates_from(const float4 &s, int32_t action, float sintheta, float costheta, float &x_dot, float &theta_dot)
+{
+    x_dot = s.y;
+    theta_dot = s.w;
     if constexpr (V == kRefTyped) {
         // expression types as written in sim.cpp:70-83
         const float force = (action == 1 ? FORCE_MAG : -FORCE_MAG);
-        float sintheta, costheta;
-        sincosf(theta, &sintheta, &costheta);  // one range reduction for both (sim.cpp:71-72 calls cosf and sinf)
         const float temp = (force + POLEMASS_LENGTH * theta_dot * theta_dot * sintheta) / TOTAL_MASS;
         const float thetaacc =
             (GRAVITY * sintheta - costheta * temp) / (LENGTH * (4.0 / 3.0 - MASSPOLE * costheta * costheta / TOTAL_MASS));
         const float xacc = temp - POLEMASS_LENGTH * thetaacc * costheta / TOTAL_MASS;
-        x = x + TAU * x_dot;
         x_dot = x_dot + TAU * xacc;
-        theta = theta + TAU * theta_dot;
         theta_dot = theta_dot + TAU * thetaacc;
-        s = make_float4(x, x_dot, theta, theta_dot);
-        // sim.cpp:88-91
-        return x < -X_THRESHOLD || x > X_THRESHOLD || theta < -THETA_THRESHOLD || theta > THETA_THRESHOLD;
     } else if constexpr (V == kLean || V == kLeanBounded) {
         constexpr double kInvMass = 1.0 / TOTAL_MASS;                            // 1 / 1.1
         constexpr double kPoleOverMass = POLEMASS_LENGTH / TOTAL_MASS;           // 0.05 / 1.1
         constexpr double kFourThirdsLength = LENGTH * 4.0 / 3.0;                 // 0.5 * 4/3
-        float sintheta, costheta;
-        if constexpr (V == kLeanBounded) sincos_bounded(theta, &sintheta, &costheta);
-        else sincosf(theta, &sintheta, &costheta);
         const double sn = sintheta, cs = costheta, td = theta_dot;
         const double force = action == 1 ? (double)FORCE_MAG : -(double)FORCE_MAG;
         const float temp = (float)(__builtin_fma((POLEMASS_LENGTH * td) * td, sn, force) * kInvMass);
@@ -175,19 +186,12 @@ template <int V> __device__ __forceinline__ bool advance(float4 &s, int32_t acti
         const float thetaacc = (float)q;
         const double ta = thetaacc;
         const float xacc = (float)__builtin_fma(-kPoleOverMass * ta, cs, (double)temp);
-        const double xd = x_dot;
-        x = (float)__builtin_fma(TAU, xd, (double)x);
-        x_dot = (float)__builtin_fma(TAU, (double)xacc, xd);
-        theta = (float)__builtin_fma(TAU, td, (double)theta);
+        x_dot = (float)__builtin_fma(TAU, (double)xacc, (double)x_dot);
         theta_dot = (float)__builtin_fma(TAU, ta, td);
-        s = make_float4(x, x_dot, theta, theta_dot);
-        return out_of_bounds(x, theta);
     } else {
         constexpr float kInvMass = (float)(1.0 / TOTAL_MASS);
         constexpr float kPoleOverMass = (float)(POLEMASS_LENGTH / TOTAL_MASS);
         constexpr float kFourThirdsLength = (float)(LENGTH * 4.0 / 3.0);
-        float sintheta, costheta;
-        sincos_bounded(theta, &sintheta, &costheta);
         const float force = action == 1 ? (float)FORCE_MAG : -(float)FORCE_MAG;
         const float temp = __builtin_fmaf(((float)POLEMASS_LENGTH * theta_dot) * theta_dot, sintheta, force) * kInvMass;
         const float num = __builtin_fmaf((float)GRAVITY, sintheta, -(costheta * temp));
@@ -197,13 +201,47 @@ template <int V> __device__ __forceinline__ bool advance(float4 &s, int32_t acti
         q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
         const float thetaacc = q;
         const float xacc = __builtin_fmaf(-kPoleOverMass * thetaacc, costheta, temp);
-        const float nx = __builtin_fmaf((float)TAU, x_dot, x);
-        const float nxd = __builtin_fmaf((float)TAU, xacc, x_dot);
-        const float nt = __builtin_fmaf((float)TAU, theta_dot, theta);
-        const float ntd = __builtin_fmaf((float)TAU, thetaacc, theta_dot);
-        s = make_float4(nx, nxd, nt, ntd);
-        return out_of_bounds(nx, nt);
+        x_dot = __builtin_fmaf((float)TAU, xacc, x_dot);
+        theta_dot = __builtin_fmaf((float)TAU, thetaacc, theta_dot);
     }
+}
+
+// The expensive half for the K worlds of a thread.  With the bounded sin / cos all K polynomials run unconditionally and
+// ONE branch per thread covers the (never taken, for a live pole) library call: the arithmetic of the K worlds is then one
+// straight line of code the scheduler interleaves, with its double-precision constants set up once.
+template <int V, int K>
+__device__ __forceinline__ void next_rates(const float4 (&s)[K], const int32_t (&action)[K], float (&x_dot)[K], float (&theta_dot)[K])
+{
+    float sn[K], cs[K];
+    if constexpr (V == kRefTyped || V == kLean) {
+#pragma unroll
+        for (int u = 0; u < K; u++) sincosf(s[u].z, &sn[u], &cs[u]);  // one range reduction for both (sim.cpp:71-72 calls cosf and sinf)
+    } else {
+        bool wide = false;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            sincos_poly(s[u].z, &sn[u], &cs[u]);
+            wide |= !(fabsf(s[u].z) <= kQuarterPi);
+        }
+        if (wide) {
+#pragma unroll
+            for (int u = 0; u < K; u++)
+                if (!(fabsf(s[u].z) <= kQuarterPi)) sincosf(s[u].z, &sn[u], &cs[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < K; u++) rates_from<V>(s[u], action[u], sn[u], cs[u], x_dot[u], theta_dot[u]);
+}
+
+// sim.cpp:68-96 for the K worlds of a thread; over[u] = world u's done flag
+template <int V, int K> __device__ __forceinline__ void advance(float4 (&s)[K], const int32_t (&action)[K], bool (&over)[K])
+{
+    float x[K], theta[K], x_dot[K], theta_dot[K];
+#pragma unroll
+    for (int u = 0; u < K; u++) over[u] = next_pose<V>(s[u], x[u], theta[u]);
+    next_rates<V, K>(s, action, x_dot, theta_dot);
+#pragma unroll
+    for (int u = 0; u < K; u++) s[u] = make_float4(x[u], x_dot[u], theta[u], theta_dot[u]);
 }
 
 constexpr int kUnroll = 4;  // worlds per thread whose loads are in flight together
@@ -236,12 +274,13 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step(uint32_t n, uint32_t
             s[u] = state[ic];
             a[u] = action[ic];
         }
+        bool finishes[kUnroll];
+        advance<V, kUnroll>(s, a, finishes);  // (rounds past the end run on world `first`'s values and are dropped)
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t i = i0 + u * kBlock;
-            bool over = false;
+            const bool over = finishes[u] && i < last;
             if (i < last) {
-                over = advance<V>(s[u], a[u]);
                 state[i] = s[u];
                 reward[i] = 1.f;
                 done[i] = over ? 1 : 0;
@@ -330,8 +369,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_reset(uint32_t n, uint32_
 // HBM: what the healing look-back of the single-launch step calls for a workgroup whose own count has not appeared
 // (episode_scan.hpp).  Inlined: a call would give the kernel a stack in scratch memory.  It never runs on an idle GPU.
 template <int V>
-__device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *action, const float4 *state, uint32_t j,
-                                                             bool sampled, uint64_t sample_seed, uint32_t sample_step)
+__device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const float4 *state, uint32_t j)
 {
     constexpr uint32_t kChunk = kUnroll * kBlock;
     const uint32_t lane = threadIdx.x & 63u;
@@ -339,35 +377,73 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
     uint32_t count = 0;
     for (uint32_t i0 = first; i0 < last; i0 += 64u) {
         const uint32_t i = i0 + lane, ic = i < last ? i : first;
-        float4 s = state[ic];
-        const int32_t a = sampled ? (int32_t)(mrl::policy_hash(sample_seed, sample_step, ic, 0) >> 31) : action[ic];
-        const bool over = i < last && advance<V>(s, a);
+        const float4 s = state[ic];
+        float x, theta;
+        const bool over = next_pose<V>(s, x, theta) && i < last;  // (the flag does not depend on the action)
         count += (uint32_t)__popcll(__ballot(over));
     }
     return count;
 }
 
-// The whole step in one launch (mrl_step / mrl_step_with_actions on one GPU): workgroup b owns
-// worlds [1024 b, 1024 b + 1024), four per thread, all in registers from the first load to the
-// last store.  Finished worlds get their episode index from the single-launch look-back of
-// episode_scan.hpp (a count that does not appear is recounted from that workgroup's inputs: no
-// workgroup ever depends on another one making progress) and are written once, already re-seeded;
-// the two-launch pair above stays for the sharded path, whose episode base comes from the other
-// ranks between the phases.  A workgroup stores its worlds' state only after its count is globally
-// visible (the publishing wave waits for its store before the barrier everybody passes).
+// The whole step in one launch (mrl_step / mrl_step_with_actions on one GPU): workgroup b owns worlds [1024 b, 1024 b + 1024),
+// four per thread, all in registers from the first load to the last store.  Finished worlds get their episode index from
+// the single-launch look-back of episode_scan.hpp (a count that does not appear is recounted from that workgroup's
+// inputs: no workgroup ever depends on another one making progress) and are written once, already re-seeded; the
+// two-launch pair above stays for the sharded path, whose episode base comes from the other ranks between the phases.
+//
+// Order of events in a workgroup (round 4): state loads, then action loads; new position and angle of its 1024 worlds (two
+// multiply-adds each) -> who finishes -> the count is PUBLISHED ~30 instructions after the state has arrived; the first wave
+// asks for the lower workgroups' counts right away (they were dispatched earlier and are ahead); then everybody runs the
+// expensive half of the transition, under which the count's acknowledgement and the look-back's answers come in; one
+// barrier; all stores.  A workgroup stores its worlds' state only after its count is globally visible (a healing
+// workgroup that does not see the count reads the state as the step's input).  The finished worlds of a wave -- a dozen
+// of its 256 under a random policy -- are re-seeded by as many lanes in ONE pass over a list in LDS (the seed hash is
+// ~150 dependent instructions; per round it would run four times for three lanes each).
+// The look-back has two levels: a workgroup's status word (32 bits) and, per GROUP of 256 consecutive workgroups, the
+// group's total, published by the group's last workgroup once its own look-back over the other 255 is done.  A workgroup
+// needs the words of the lower workgroups of its own group (up to four per lane) and the totals of the lower groups (up to
+// sixteen in all).  Batches of up to 262144 worlds are one group: one hand-off through memory, ~1.5 us under the other
+// waves' traffic; larger ones pay a second for the group totals.  (Round 4 measured the flat form first -- every workgroup
+// reading all lower status words, up to sixteen per lane at 1 M worlds: the 4 KB those words occupy are one hot spot that
+// a million uncached loads queue on, 3-5 us per look-back, profiles/r04_e_cartpole_fused_timeline_flat_lookback.txt --
+// and asking for the words BEFORE the expensive half: they come back stale, the workgroups around publish at the same
+// moment, and the second asking queues behind the first.)  A group total that does not appear is replaced by its 256 status
+// words, a status word that does not appear by a recount: nothing waits on another workgroup.
+constexpr uint32_t kGroup = 256;
+constexpr int kGroupWords = kGroup / 64;  // status words per lane
+
 template <int V>
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
-                                                                  int32_t *__restrict__ done, unsigned long long *status,
+                                                                  int32_t *__restrict__ done, uint32_t *status,
+                                                                  unsigned long long *group_total,
                                                                   uint32_t epoch, const uint32_t *episode_base,
                                                                   uint32_t *next_counter,
                                                                   uint32_t *__restrict__ reset_count,
                                                                   int32_t *action_out, uint64_t sample_seed, uint32_t sample_step,
-                                                                  const mrl::HealTest heal, const mrl::DeviceCounter device_counter)
+                                                                  const mrl::HealTest heal, const mrl::DeviceCounter device_counter
+#ifdef MRL_DIAG
+                                                                  , unsigned long long *stamps  // diagnostic build: s_memrealtime stamps per wave
+#endif
+)
 {
+#ifdef MRL_DIAG
+#define CP_STAMP(k)                                                                                                        \
+    do {                                                                                                                  \
+        if (stamps && (threadIdx.x & 63u) == 0) stamps[(size_t)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define CP_STAMP(k) do { } while (0)
+#endif
+    CP_STAMP(0);
+    // Four workgroups share a CU, one wave of each per SIMD, and the SIMD issues its oldest wave's vector instructions
+    // first: without this a wave of a high workgroup whose state has arrived sits behind the lower workgroups' expensive
+    // halves (~0.5 us each) before it can even count its finished worlds -- and everybody above waits for that count.
+    __builtin_amdgcn_s_setprio(3);
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_votes[kUnroll][kBlock / 64];
     __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_list[kBlock / 64][kUnroll * 64];  // per wave: its finished worlds, (rank in the workgroup << 16) | local index
     const uint32_t b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
     const bool last_block = b == gridDim.x - 1;
@@ -379,8 +455,12 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
-        const uint32_t ic = i < last ? i : first;  // clamped: loads stay in bounds
-        s[u] = state[ic];
+        s[u] = state[i < last ? i : first];  // clamped: loads stay in bounds
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {  // the actions are not needed before the expensive half: behind the state in the queue
+        const uint32_t i = first + u * kBlock + threadIdx.x;
+        const uint32_t ic = i < last ? i : first;
         if (action_out) {
             a[u] = (int32_t)(mrl::policy_hash(sample_seed, sample_step, ic, 0) >> 31);
             if (i < last) action_out[i] = a[u];
@@ -388,47 +468,81 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
             a[u] = action[ic];
         }
     }
-    // the finished worlds, as one ballot per round and wave (round u covers worlds first + 256 u ...: ascending world
-    // order = round, then wave, then lane); every hand-off below goes through LDS only -- a __syncthreads would also
-    // wait for the wave's outstanding stores to be acknowledged, microseconds while the whole GPU is storing
+    // First the cheap half of the transition: new position and angle, hence the finished worlds -- one ballot per round
+    // and wave (round u covers worlds first + 256 u ...: ascending world order = round, then wave, then lane).  Every
+    // hand-off below goes through LDS only: a __syncthreads would also wait for the wave's outstanding stores to be
+    // acknowledged, microseconds while the whole GPU is storing.
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool over[kUnroll];
     unsigned long long votes[kUnroll];
+    float nx[kUnroll], ntheta[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
-        over[u] = i < last && advance<V>(s[u], a[u]);
+        over[u] = next_pose<V>(s[u], nx[u], ntheta[u]) && i < last;
         votes[u] = __ballot(over[u]);
         if (lane == 0) s_votes[u][wave] = (uint32_t)__popcll(votes[u]);
     }
+    CP_STAMP(1);
     mrl::lds_barrier();
-    uint32_t block_total = 0, before_me[kUnroll];
+    uint32_t block_total = 0, wave_total = 0;
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
-        before_me[u] = block_total;
+        uint32_t before_me = block_total;
         for (uint32_t w = 0; w < kBlock / 64; w++) {
             const uint32_t c = s_votes[u][w];
-            before_me[u] += w < wave ? c : 0u;
+            before_me += w < wave ? c : 0u;
             block_total += c;
         }
-        before_me[u] += (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
+        const uint32_t below = (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
+        if (over[u]) s_list[wave][wave_total + below] = ((before_me + below) << 16) | (uint32_t)(u * kBlock + threadIdx.x);
+        wave_total += (uint32_t)__popcll(votes[u]);
     }
-    // the count is globally visible before any wave of this workgroup overwrites a world's state (a healing workgroup
-    // that does not see the count reads the state as the step's input): the publishing wave waits for ITS stores only
-    if (wave == 0) {
-        if (lane == 0) mrl::publish_count(status, b, epoch, block_total);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the count leaves ~30 instructions after the state has come in and travels while the expensive half runs
+    if (wave == 0 && lane == 0) mrl::publish_count(status, b, epoch, block_total);
+    const bool needs_prefix = block_total != 0 || last_block;  // uniform per workgroup
+    const uint32_t group = b / kGroup, group_first = group * kGroup;
+    const bool closes_group = b + 1 == group_first + kGroup;   // the group's last workgroup publishes the group's total
+    const bool looks_back = wave == 0 && (needs_prefix || closes_group);
+    CP_STAMP(2);
+    __builtin_amdgcn_s_setprio(0);
+    // (sin, cos, the accelerations: ~2 us of issue per SIMD at 1 M worlds)
+    {
+        float nxd[kUnroll], nthd[kUnroll];
+        next_rates<V, kUnroll>(s, a, nxd, nthd);
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            asm volatile("" : "+v"(nxd[u]), "+v"(nthd[u]));  // here, not sunk into the store phase
+            s[u] = make_float4(nx[u], nxd[u], ntheta[u], nthd[u]);
+        }
     }
+    CP_STAMP(3);
+    __builtin_amdgcn_s_setprio(3);
+    // the count is globally visible before any wave of this workgroup overwrites a world's state: the publishing wave waits
+    // for ITS store, long acknowledged by now
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mrl::lds_barrier();
-    // the first wave looks back BEFORE its own stores (a load would otherwise sit out their acknowledgement) ...
-    if (wave == 0 && (block_total != 0 || last_block)) {
-        const bool sampled = action_out != nullptr;
-        const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
-            return recount_chunk<V>(n, action, state, j, sampled, sample_seed, sample_step);
-        });
-        if (lane == 0) s_prefix = before;
+    CP_STAMP(4);
+    if (looks_back) {  // (wave 0) before its own stores: a load would sit out their acknowledgement
+        auto recount = [&](uint32_t j) { return recount_chunk<V>(n, state, j); };
+        uint32_t lower[kGroupWords];
+        unsigned long long lower_groups[1];
+        mrl::lookback_issue<kGroupWords>(status, group_first, b, lower);
+        mrl::lookback_issue<1>(group_total, 0, needs_prefix ? group : 0u, lower_groups);
+        const uint32_t in_group = mrl::wave_sum(mrl::lookback_finish<kGroupWords>(status, group_first, b, epoch, heal, lower, recount));
+        if (closes_group && lane == 0) mrl::publish_count(group_total, group, epoch, in_group + block_total);
+        if (needs_prefix) {
+            auto regroup = [&](uint32_t g) {  // a group total that has not appeared: the group's 256 words instead
+                uint32_t words[kGroupWords];
+                mrl::lookback_issue<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, words);
+                return mrl::wave_sum(mrl::lookback_finish<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, epoch, heal, words, recount));
+            };
+            const uint32_t below = mrl::wave_sum(mrl::lookback_finish<1>(group_total, 0, group, epoch, mrl::HealTest{}, lower_groups, regroup));
+            if (lane == 0) s_prefix = below + in_group;
+        }
     }
-    // ... while everything that does not need the prefix goes out
+    CP_STAMP(5);
+    // everything that does not need the prefix goes out (the other three waves are here right after the barrier)
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
@@ -438,12 +552,15 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
             done[i] = over[u] ? 1 : 0;
         }
     }
-    if (block_total == 0 && !last_block) return;  // uniform per workgroup
+    CP_STAMP(6);
+    if (!needs_prefix) return;
     mrl::lds_barrier();
     const uint32_t prefix = s_prefix;
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++)
-        if (over[u]) state[first + u * kBlock + threadIdx.x] = fresh_state(base + prefix + before_me[u]);
+    for (uint32_t e = lane; e < wave_total; e += 64u) {  // this wave's finished worlds, one per lane
+        const uint32_t entry = s_list[wave][e];
+        state[first + (entry & 0xffffu)] = fresh_state(base + prefix + (entry >> 16));
+    }
+    CP_STAMP(7);
     if (last_block && threadIdx.x == 0) {
         const uint32_t grand_total = prefix + block_total;  // the whole GPU's
         *reset_count = grand_total;
@@ -486,12 +603,19 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
         unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
         const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
         bool over[kUnroll];
+        int32_t drawn[kUnroll];
         uint32_t finished = 0;
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t i = first + u * kBlock + threadIdx.x;
-            const int32_t a = (int32_t)(mrl::policy_hash(seed, first_step + k, i < last ? i : first, 0) >> 31);
-            over[u] = i < last && advance<V>(s[u], a);
+            drawn[u] = (int32_t)(mrl::policy_hash(seed, first_step + k, i < last ? i : first, 0) >> 31);
+        }
+        advance<V, kUnroll>(s, drawn, over);
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t i = first + u * kBlock + threadIdx.x;
+            const int32_t a = drawn[u];
+            over[u] = over[u] && i < last;
             finished += over[u] ? 1u : 0u;
             if (i < last) {
                 action_out[i] = a;
@@ -603,7 +727,8 @@ struct CartpoleSim final : mrl_sim {
     uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     uint32_t parity = 0;
     // single-launch step (see mrl_cartpole_step_fused)
-    unsigned long long *status = nullptr;
+    uint32_t *status = nullptr;
+    unsigned long long *group_total = nullptr;  // per 64 workgroups (see mrl_cartpole_step_fused)
     mrl::AlarmOwner alarm;
     mrl::HealTest heal;  // test hook of the healing look-back (mrl_debug_set fused_heal_test)
     uint32_t fused_grid = 0, epoch = 0;
@@ -612,6 +737,9 @@ struct CartpoleSim final : mrl_sim {
     void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     bool scan_timed_out() const override { return alarm.raised(); }
 
+#ifdef MRL_DIAG
+    unsigned long long *stamps = nullptr;
+#endif
     bool fused_step = false;  // one launch with the self-healing in-kernel look-back (the default where the grid allows; mrl_debug_set fused_step 2: two launches)
 
     void step(const int32_t *actions, hipStream_t stream) override
@@ -629,8 +757,12 @@ struct CartpoleSim final : mrl_sim {
         if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
         with_variant(variant, [&](auto v) {
             hipLaunchKernelGGL(mrl_cartpole_step_fused<decltype(v)::value>, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds,
-                               actions, state, reward, done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count,
-                               action_out, seed, sample_step, heal, launch_state.counter_args(counter));
+                               actions, state, reward, done, status, group_total, epoch, counter + parity, counter + (parity ^ 1u), reset_count,
+                               action_out, seed, sample_step, heal, launch_state.counter_args(counter)
+#ifdef MRL_DIAG
+                               , stamps
+#endif
+            );
         });
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -740,6 +872,12 @@ struct CartpoleSim final : mrl_sim {
         case MRL_CARTPOLE_RESET_COUNT: *out = mrl::make_desc(reset_count, MRL_UINT32, device, {1}); return true;
         case MRL_CARTPOLE_SCAN_TIMEOUT: *out = mrl::make_desc(alarm.alarm().dev, MRL_UINT32, device, {1}); return true;
         case MRL_CARTPOLE_SHARD_COUNT: *out = mrl::make_desc(shard_count, MRL_UINT32, device, {1}); return true;
+#ifdef MRL_DIAG
+        case 14:
+            if (!stamps) return false;
+            *out = mrl::make_desc(stamps, MRL_UINT8, device, {(int64_t)fused_grid * (kBlock / 64) * 8 * 8});
+            return true;
+#endif
         default: return false;
         }
     }
@@ -792,19 +930,23 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             const uint32_t blocks = (num_worlds + kUnroll * kBlock - 1) / (kUnroll * kBlock);
             if (blocks <= mrl::kMaxFusedBlocks) {
                 sim->fused_grid = blocks;
-                sim->status = sim->arena.alloc<unsigned long long>(blocks);
+                sim->status = sim->arena.alloc<uint32_t>(blocks);
+                sim->group_total = sim->arena.alloc<unsigned long long>((blocks + kGroup - 1) / kGroup);
+#ifdef MRL_DIAG
+                if (mrl::debug_get("stamps", 0)) sim->stamps = sim->arena.alloc<unsigned long long>((size_t)blocks * (kBlock / 64) * 8);
+#endif
             }
         }
         sim->alarm.init(sim->arena);
         sim->launch_state.init(sim->arena);
         {
-            // mrl_debug_set fused_step: 0 = the library's choice by batch size, 1 = one launch, 2 = always two.  One launch
-            // wins while the host's call rate is the bound, two once the GPU is: in the single launch every workgroup ends
-            // with look-back + ranking + re-seeding behind its stores, in the pair that tail is a launch of its own that only
-            // touches the finished worlds (tools/fused_crossover.py, us per step one / two launches: 32 worlds 3.8 / 7.6,
-            // 1000 5.9 / 7.4, 10000 7.7 / 7.3, 100000 8.7 / 7.2, 1 M 15.2 / 14.2)
+            // mrl_debug_set fused_step: 0 = the library's choice, 1 = one launch, 2 = always two.  Since round 4 (count published
+            // before the expensive half, two-level look-back) one launch wins at every size it exists for -- us per step one /
+            // two launches, actions from a pool of eight tensors: 4096 worlds 4.3 / 6.1, 100 000 5.1 / 6.6, 262 144 6.2 / 9.7,
+            // 524 288 7.7 / 9.6, 1 M 10.7 / 12.3 (tools/cartpole_probe.py, profiles/r04_i_cartpole_probe.txt); round 3's
+            // crossover was 4096 worlds.  Two launches remain for the sharded path and above 4 M worlds (kMaxFusedBlocks).
             const int64_t knob = mrl::debug_get("fused_step", 0);
-            sim->fused_step = knob == 1 || (knob == 0 && num_worlds <= kFusedStepMaxWorlds);
+            sim->fused_step = knob != 2;
             sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
             sim->heal.seen = sim->arena.alloc<uint32_t>(sim->fused_grid ? sim->fused_grid : 1);
         }

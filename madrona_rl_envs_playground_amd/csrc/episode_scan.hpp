@@ -181,6 +181,18 @@ __device__ __forceinline__ void publish_count(unsigned long long *status, uint32
 {
     __hip_atomic_store(&status[block], ((unsigned long long)epoch << 32) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// A status word in 32 bits, for kernels whose look-back keeps many of them in registers: the count in the low 12 bits
+// (a workgroup of at most 4095 finishing worlds), the low 20 bits of the epoch above.  Twenty bits are enough BECAUSE EVERY
+// WORKGROUP PUBLISHES IN EVERY LAUNCH: the word of a workgroup that has not published yet carries the previous launch's
+// epoch, never one 2^20 launches old.
+__device__ __forceinline__ void publish_count(uint32_t *status, uint32_t block, uint32_t epoch, uint32_t count)
+{
+    __hip_atomic_store(&status[block], (epoch << 12) | (count & 0xfffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool status_is(unsigned long long word, uint32_t epoch) { return (uint32_t)(word >> 32) == epoch; }
+__device__ __forceinline__ bool status_is(uint32_t word, uint32_t epoch) { return (word >> 12) == (epoch & 0xfffffu); }
+__device__ __forceinline__ uint32_t status_count(unsigned long long word) { return (uint32_t)word; }
+__device__ __forceinline__ uint32_t status_count(uint32_t word) { return word & 0xfffu; }
 
 // Sum of the counts status[first .. first + stride * kBatch) visible to this thread (index first + lane + stride j),
 // waiting for each word's epoch tag.  All loads of the batch are issued before the first tag is looked
@@ -237,56 +249,83 @@ __device__ __forceinline__ void heal_test_delay(const HealTest &t, uint32_t bloc
     __syncthreads();
 }
 
-// Sum of the counts of workgroups [0, block) for `epoch`, to every lane of the calling wave.  recount(i) is called
-// by the WHOLE wave (uniform i) and returns workgroup i's count to every lane.
-template <typename Recount>
-__device__ __forceinline__ uint32_t wave_prefix_or_recount(const unsigned long long *status, uint32_t block, uint32_t epoch,
-                                                           const HealTest &test, Recount &&recount)
+// The look-back in two halves, so that a kernel can put work between asking for the status words and needing them:
+// lookback_issue requests the words of workgroups [first, min(limit, first + 64 K)) -- K per lane, all loads in flight
+// together -- and lookback_finish turns them into this lane's share of the sum (to be added up over the wave by the
+// caller, see wave_sum): words that have not appeared are asked for again TOGETHER (one round trip per poll, not one per
+// word: under the other waves' row stores a round trip is ~2 us), and after kHealPolls polls recount(i) -- called by the
+// WHOLE wave with a uniform i, returning workgroup i's count to every lane -- replaces the wait.
+template <int K, typename Word>
+__device__ __forceinline__ void lookback_issue(const Word *status, uint32_t first, uint32_t limit, Word (&v)[K])
 {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t before = 0;
-    for (uint32_t first = 0; first < block; first += 64u * 8u) {
-        unsigned long long v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t i = first + lane + 64u * j;
-            v[j] = i < block ? __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        }
-        // all words that have not appeared are asked for again TOGETHER (one round trip per poll, not one per word:
-        // under the other waves' row stores a round trip is ~2 us)
-        uint32_t missing = 0;
+    for (int j = 0; j < K; j++) {
+        const uint32_t i = first + lane + 64u * j;
+        v[j] = i < limit ? __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (Word)0;
+    }
+}
+
+template <int K, typename Word, typename Recount>
+__device__ __forceinline__ uint32_t lookback_finish(const Word *status, uint32_t first, uint32_t limit, uint32_t epoch,
+                                                    const HealTest &test, Word (&v)[K], Recount &&recount)
+{
+    static_assert(K <= 32, "one bit per word in `missing`");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t before = 0, missing = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) missing |= (first + lane + 64u * j < block && (uint32_t)(v[j] >> 32) != epoch) ? 1u << j : 0u;
-        for (uint32_t polls = 0; polls < kHealPolls && __ballot(missing != 0) != 0ull; polls++) {
-            __builtin_amdgcn_s_sleep(2);
+    for (int j = 0; j < K; j++) missing |= (first + lane + 64u * j < limit && !status_is(v[j], epoch)) ? 1u << j : 0u;
+    for (uint32_t polls = 0; polls < kHealPolls && __ballot(missing != 0) != 0ull; polls++) {
+        __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((missing >> j) & 1u) v[j] = __hip_atomic_load(&status[first + lane + 64u * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < K; j++)
+            if ((missing >> j) & 1u) v[j] = __hip_atomic_load(&status[first + lane + 64u * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((uint32_t)(v[j] >> 32) == epoch) missing &= ~(1u << j);
-        }
+        for (int j = 0; j < K; j++)
+            if (status_is(v[j], epoch)) missing &= ~(1u << j);
+    }
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (first + lane + 64u * j < block && !((missing >> j) & 1u)) before += (uint32_t)v[j];
-        if (__ballot(missing != 0) == 0ull) continue;
-        for (int j = 0; j < 8; j++) {
-            unsigned long long todo = __ballot((missing >> j) & 1u);
-            while (todo) {
-                const uint32_t src = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const uint32_t i = first + src + 64u * j;  // wave-uniform
-                uint32_t c = recount(i);
-                // a count that has appeared meanwhile wins: the inputs just read may already have been overwritten
-                const unsigned long long now = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(now >> 32) == epoch) c = (uint32_t)now;
-                if (test.mod && lane == 0) __hip_atomic_store(&test.seen[i], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                before += lane == src ? c : 0u;
-            }
+    for (int j = 0; j < K; j++)
+        if (first + lane + 64u * j < limit && !((missing >> j) & 1u)) before += status_count(v[j]);
+    if (__ballot(missing != 0) == 0ull) return before;
+    for (int j = 0; j < K; j++) {
+        unsigned long long todo = __ballot((missing >> j) & 1u);
+        while (todo) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t i = first + src + 64u * j;  // wave-uniform
+            uint32_t c = recount(i);
+            // A count that has appeared meanwhile wins: the inputs just read may already have been overwritten.  That
+            // only works if the recount's loads are performed BEFORE the status word is read again -- the recount's result
+            // depends on them, but nothing else orders two loads of one wave, so wait for them here (cold path).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const Word now = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (status_is(now, epoch)) c = status_count(now);
+            if (test.mod && lane == 0) __hip_atomic_store(&test.seen[i], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before += lane == src ? c : 0u;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
     return before;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+{
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Sum of the counts of workgroups [from, block) for `epoch`, to every lane of the calling wave.
+template <typename Word, typename Recount>
+__device__ __forceinline__ uint32_t wave_prefix_or_recount(const Word *status, uint32_t block, uint32_t epoch,
+                                                           const HealTest &test, Recount &&recount, uint32_t from = 0)
+{
+    uint32_t before = 0;
+    for (uint32_t first = from; first < block; first += 64u * 8u) {
+        Word v[8];
+        lookback_issue<8>(status, first, block, v);
+        before += lookback_finish<8>(status, first, block, epoch, test, v, recount);
+    }
+    return wave_sum(before);
 }
 
 }  // namespace mrl

@@ -173,7 +173,7 @@ def test_hanabi_65536_worlds_lockstep_vs_oracle(hip_lib, oracle_lib):
     import os
     n = 65536
     sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **HANABI_FULL)
-    assert sim.kernel_name == "mrl_hanabi_step_fused" and sim.launch_shape[0] == 256
+    assert sim.kernel_name == "mrl_hanabi_step_fused"
     orc = oracle_lib.HanabiOracle(HANABI_FULL, n, num_threads=min(16, os.cpu_count() or 1))
     _hanabi_equal(sim, orc, "initial")
     rng = np.random.default_rng(65536)
@@ -234,7 +234,7 @@ def test_hanabi_65536_worlds_persistent_rollout_vs_oracle(hip_lib, oracle_lib):
     sim.close()
 
 
-@pytest.mark.parametrize("fused", [0, 1], ids=["library_choice", "single_launch"])
+@pytest.mark.parametrize("fused", [0, 2], ids=["library_choice_single_launch", "two_launches"])
 def test_cartpole_one_million_worlds_lockstep_vs_oracle(fused, hip_lib, oracle_lib):
     """1 048 576 worlds x 30 random-action steps against the oracle with the resync protocol of
     tests/test_gpu_cartpole.py::test_lockstep_vs_oracle: one-step differential at 1e-5 (float state; the reference's own check
@@ -245,7 +245,7 @@ def test_cartpole_one_million_worlds_lockstep_vs_oracle(fused, hip_lib, oracle_l
     n = 1 << 20
     with debug_knobs({"fused_step": fused}):
         sim = CartpoleSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n)
-    assert sim.kernel_name == ("mrl_cartpole_step_fused" if fused else "mrl_cartpole_step")
+    assert sim.kernel_name == ("mrl_cartpole_step" if fused == 2 else "mrl_cartpole_step_fused")
     orc = oracle_lib.CartpoleOracle(n, num_threads=min(16, os.cpu_count() or 1))
     st, act = sim.observation_tensor().to_torch(), sim.action_tensor().to_torch()
     assert np.array_equal(st.cpu().numpy().view(np.uint32), orc.state.view(np.uint32)), "initial states"
