@@ -179,7 +179,12 @@ typedef struct mrl_hanabi_config {
  *   memory: the reference fills the state by copying the observation and appending the
  *   own hand (generateObsState, sim.cpp:367-379), so the two tensors agree on those
  *   bytes by construction, always (also for the agent whose buffers stay stale: both
- *   are refreshed together), and this engine writes them once.
+ *   are refreshed together), and this engine writes them once.  For a configuration
+ *   smaller than the full game (fewer colours / tokens) the observation has fewer than
+ *   658 entries and OBSERVATION is exported exactly that wide, (2, N, obs_size): the row
+ *   continues with the agent's own hand, which is hidden from the observer (the reference
+ *   declares 658 entries whatever the configuration; its wrappers read [:obs_size],
+ *   envs/hanabi_env.py:92-104).
  *   GAME uint8 (N, 176): the raw per-world game record (tests only; layout in
  *   csrc/hanabi.hip); RESET_COUNT uint32 (1): worlds that finished in the last completed step (written by
  *   phase 2); SHARD_COUNT uint32 (1): worlds that finished in the last mrl_step_phase1 -- what the ranks of a

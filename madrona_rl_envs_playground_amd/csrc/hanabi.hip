@@ -71,8 +71,8 @@ constexpr int kEncWords = 27;    // 25 words of bits + legal-move mask + spare (
 // whose buffers stay stale: both are refreshed together or not at all.  Writing those 658 bytes once
 // instead of twice takes 42 % off the bytes of a step (rounds 1-2 wrote [state 784 | observation 672 |
 // mask 80] = 1536 bytes per agent).  For configurations whose observation is shorter than 658 entries the
-// view's tail shows own-hand entries of the state where the reference's buffer holds leftovers of its
-// own; the wrappers only ever look at [:obs_size] (envs/hanabi_env.py:92-104).
+// exported view is that much narrower (the reference declares 658 whatever the configuration and its wrappers
+// look at [:obs_size], envs/hanabi_env.py:92-104): the row goes on with the own hand, which is not for the observer.
 // (Separate obs / state / mask arrays with 672 / 784 / 80-byte rows were measured in round 1: every
 // row end shares a line with the next row, the 80-byte mask rows most of all -- dropping the
 // mask stores alone, 5 % of the bytes, took 5 us off a 24 us kernel.)
@@ -1881,8 +1881,10 @@ struct HanabiSim final : mrl_sim {
         case MRL_HANABI_ACTIVE_AGENT: *out = mrl::make_desc(params.active, MRL_INT32, device, {2, N}); return true;
         case MRL_HANABI_ACTION: *out = mrl::make_desc(action, MRL_INT32, device, {2, N, 1}); return true;
         case MRL_HANABI_OBSERVATION:
-            // the head of the state row: the reference fills the state by copying the observation (see kAgentBlock)
-            *out = mrl::make_desc(params.rows, MRL_INT8, device, {2, N, MRL_HANABI_OBS_SIZE}, {kAgentBlock, kWorldBlock, 1});
+            // the head of the state row: the reference fills the state by copying the observation (see kAgentBlock).  As
+            // wide as THIS configuration's observation (658 for the full game): what follows in the row is the agent's own
+            // hand, which an observation must not show (the reference's buffer holds nothing there)
+            *out = mrl::make_desc(params.rows, MRL_INT8, device, {2, N, (int64_t)params.obs_bits}, {kAgentBlock, kWorldBlock, 1});
             return true;
         case MRL_HANABI_ACTION_MASK:
             *out = mrl::make_desc(params.rows + kStateRow, MRL_INT32, device, {2, N, 20}, {kAgentBlock / 4, kWorldBlock / 4, 1});

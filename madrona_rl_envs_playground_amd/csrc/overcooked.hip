@@ -2707,11 +2707,10 @@ void mrl::step_many_overcooked(mrl_sim *const *sims, uint32_t count, const int32
     m.count = count;
     for (uint32_t k = 0; k < count; k++)
         m.sim[k] = static_cast<OvercookedSim *>(sims[k])->generic_step_params(actions_or_null ? actions_or_null[k] : nullptr);
-    static uint32_t lds_allowed = 65536;
-    if (lds > lds_allowed) {
+    // hipFuncSetAttribute applies to the current device only and this entry point may be called for several devices and from
+    // several threads: no process-wide cache of "already raised" -- the call costs little next to the launch
+    if (lds > 65536)
         MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step_many), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_allowed = lds;
-    }
     hipLaunchKernelGGL(mrl_overcooked_step_many, dim3(blocks), dim3(kBlock), lds, stream, m);
     MRL_HIP(hipGetLastError());
 }

@@ -9,14 +9,18 @@ its own ``OvercookedMadrona`` (same tensors, same values: tests compare them) --
 ``"one_launch"``   ONE kernel launch for all sub-batches (``mrl_step_many``: the grid is the concatenation of the simulators'
                    grids, every workgroup runs its own simulator's step on that simulator's parameters, which travel in the
                    kernel arguments).  One host call per step, no streams, no events.  It runs the generic step kernel, so
-                   it is for many small sub-batches, where the launches are what costs.
+                   it is for many small sub-batches, where the launches are what costs.  A launch takes up to eight
+                   simulators (more are stepped eight at a time), and a simulator ``mrl_step_many`` does not take -- a large
+                   layout whose workgroups share one copy of a world (``simulators.can_step_with_others``) -- is stepped by
+                   its own call behind the shared launch.
 ``"sequential"``   one step call per layout on the caller's stream, each with its own (specialised) kernel: best once the
                    sub-batches are large enough to fill the GPU on their own.
 ``"graph"``        the fork / step / join pattern below captured ONCE as a HIP graph and replayed per step (Overcooked step
                    launches carry no host-side state, so they can be captured: INTEGRATION.md); the captured launches read
                    the simulators' ACTION tensors, so the caller's actions are copied there first.
 ``"forked_streams"`` one stream per layout, forked from and joined back into the caller's stream with events.
-``"auto"``         (default) ``one_launch`` while every sub-batch has at most 16384 worlds, ``sequential`` above.
+``"auto"``         (default) ``one_launch`` while every sub-batch has at most 16384 worlds and at least two of them can share
+                   a launch, ``sequential`` otherwise.
 
 Measured, the five standard layouts, us per step for all five sub-batches (tools/multi_layout_probe.py):
 5 x 100 worlds: one launch 11.2, sequential 25, graph 40, forked streams 110 (the event operations cost the host more than
@@ -24,7 +28,7 @@ the launches); 5 x 8192: 26.3 / 35.7 / 54 / 88; 5 x 32768: 75 / 61.5 / 80 / 130.
 """
 import torch
 
-from ..simulators import step_many
+from ..simulators import STEP_MANY_MAX, can_step_with_others, step_many
 from .overcooked_env import OvercookedMadrona
 
 ONE_LAUNCH_MAX_WORLDS = 16384
@@ -45,8 +49,12 @@ class OvercookedMultiLayout:
                      for name, n in zip(self.layouts, counts)]
         self.num_envs = sum(counts)
         self.device = self.envs[0].device
+        # who can share a launch (mrl_step_many refuses the shared-world configuration), eight at a time; the others alone
+        together = [k for k, env in enumerate(self.envs) if can_step_with_others(env.sim)]
+        self._shared = [together[i:i + STEP_MANY_MAX] for i in range(0, len(together), STEP_MANY_MAX)]
+        self._alone = [k for k in range(len(self.envs)) if k not in together]
         if mode == "auto":
-            mode = "one_launch" if max(counts) <= ONE_LAUNCH_MAX_WORLDS and len(counts) <= 8 else "sequential"
+            mode = "one_launch" if max(counts) <= ONE_LAUNCH_MAX_WORLDS and len(together) >= 2 else "sequential"
         self.mode = mode
         self._graph = None
         if mode in ("graph", "forked_streams"):
@@ -91,7 +99,13 @@ class OvercookedMultiLayout:
                     else:
                         env.static_actions.copy_(act.to(env.static_actions.device), non_blocking=True)
                         ready.append(None)         # the simulator's own ACTION tensor
-            step_many([env.sim for env in self.envs], ready)
+            for group in self._shared:
+                step_many([self.envs[k].sim for k in group], None if ready is None else [ready[k] for k in group])
+            for k in self._alone:
+                if ready is None or ready[k] is None:
+                    self.envs[k].sim.step()
+                else:
+                    self.envs[k].sim.step_with_actions(ready[k])
             return self._results()
         if self.mode == "graph":
             if actions is not None:

@@ -4,4 +4,4 @@ base of vectoragent.py).  Trainers, SB3/cleanrl agents and the process-based
 AsyncVectorEnv of the reference are consumers of this API, not part of it."""
 from .vectorobservation import VectorObservation  # noqa: F401
 from .vectoragent import RandomVectorAgent, VectorAgent  # noqa: F401
-from .vectorenv import DummyEnv, MadronaEnv, PlayerException, VectorMultiAgentEnv  # noqa: F401
+from .vectorenv import DummyEnv, MadronaEnv, PlayerException, SyncVectorEnv, VectorMultiAgentEnv  # noqa: F401

@@ -241,3 +241,99 @@ class MadronaEnv(VectorMultiAgentEnv):
 
     def n_reset(self):
         return self._observations()
+
+
+class SyncVectorEnv(VectorMultiAgentEnv):
+    """The baseline the reference measures its batched simulators against: N ordinary single-world multi-agent
+    environments stepped one after the other on the host, presented through the vector API
+    (/root/reference/pantheonrl_extension/vectorenv.py:348-457).  ``env_fns``: callables that build the environments;
+    each environment follows the reference's ``MultiAgentEnv`` protocol --
+
+        ``n_reset() -> (agents, observations)``
+        ``n_step(actions) -> (agents, observations, rewards, done, info)``
+
+    where ``agents`` are the players to act next, ``observations[j] = (obs, state, action_mask)`` numpy arrays for
+    ``agents[j]`` and ``actions`` holds one action per player that was asked to act.  A finished environment is reset at
+    once and its first observation of the next episode returned, with the last step's rewards and ``done`` (the batched
+    simulators behave the same way).  Players that are not to act keep their previous rows and are inactive.
+
+    Nothing of the HIP engine is involved: this is host-side plumbing for environments that exist only in Python.
+    (Mechanism: the reference writes every scalar straight into device tensors, several tiny copies per player and
+    world and step; here a step is assembled in host arrays and crosses to the device once per tensor.)"""
+
+    def __init__(self, env_fns, device=None):
+        if device is None:
+            device = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+        self.envs = [fn() for fn in env_fns]
+        if not self.envs:
+            raise ValueError("SyncVectorEnv needs at least one environment")
+        first = self.envs[0]
+        self.observation_space = first.observation_space
+        self.action_space = first.action_space
+        self.share_observation_space = first.share_observation_space
+        super().__init__(len(self.envs), device=device, n_players=first.n_players)
+        self.agents_tuples = []
+        self._host = None  # host-side staging arrays, allocated from the first observation's shapes
+
+    def _allocate(self, sample):
+        obs, state, mask = (np.asarray(part) for part in sample)
+        P, N = self.n_players, self.num_envs
+        self._host = {
+            "active": np.zeros((P, N), dtype=bool),
+            "obs": np.zeros((P, N) + obs.shape, dtype=np.float32),
+            "state": np.zeros((P, N) + state.shape, dtype=np.float32),
+            "mask": np.ones((P, N) + mask.shape, dtype=bool),
+        }
+
+    def _place(self, world, agents, observations):
+        host = self._host
+        host["active"][:, world] = False
+        for agent, (obs, state, mask) in zip(agents, observations):
+            host["active"][agent, world] = True
+            host["obs"][agent, world] = obs
+            host["state"][agent, world] = state
+            host["mask"][agent, world] = mask
+
+    def _publish(self):
+        host = self._host
+        self.static_active_agents = torch.from_numpy(host["active"]).to(self.device)
+        self.static_observations = torch.from_numpy(host["obs"]).to(self.device)
+        self.static_agent_states = torch.from_numpy(host["state"]).to(self.device)
+        self.static_action_masks = torch.from_numpy(host["mask"]).to(self.device)
+        return [VectorObservation(self.static_active_agents[p], self.static_observations[p], self.static_agent_states[p],
+                                  self.static_action_masks[p]) for p in range(self.n_players)]
+
+    def n_reset(self):
+        self.agents_tuples = []
+        for world, env in enumerate(self.envs):
+            agents, observations = env.n_reset()
+            if self._host is None:
+                self._allocate(observations[0])
+            self.agents_tuples.append(tuple(agents))
+            self._place(world, agents, observations)
+        return self._publish()
+
+    def n_step(self, actions):
+        """``actions``: (n_players, num_envs, ...) -- only the entries of the players that were asked to act are used."""
+        acts = actions.detach().cpu().numpy() if torch.is_tensor(actions) else np.asarray(actions)
+        rewards = np.zeros((self.n_players, self.num_envs), dtype=np.float32)
+        dones = np.zeros(self.num_envs, dtype=bool)
+        infos = []
+        for world, env in enumerate(self.envs):
+            asked = tuple(acts[agent, world] for agent in self.agents_tuples[world])
+            agents, observations, rews, done, info = env.n_step(asked)
+            if done:
+                agents, observations = env.n_reset()
+            self.agents_tuples[world] = tuple(agents)
+            rewards[:, world] = np.asarray(rews, dtype=np.float32)[:self.n_players]
+            dones[world] = bool(done)
+            infos.append(info)
+            self._place(world, agents, observations)
+        self.static_rewards = torch.from_numpy(rewards).to(self.device)
+        self.static_dones = torch.from_numpy(dones).to(self.device)
+        return self._publish(), self.static_rewards, self.static_dones, infos
+
+    def close(self, **kwargs):
+        for env in self.envs:
+            if hasattr(env, "close"):
+                env.close()

@@ -377,6 +377,15 @@ class OvercookedSimulator(_Simulator):
     def state_timestep_tensor(self): return self._tensor(13)
 
 
+STEP_MANY_MAX = 8  # simulators per launch (the kernel arguments hold that many parameter blocks: mrl_step_many)
+
+
+def can_step_with_others(sim):
+    """May ``sim`` take part in ``step_many``?  Overcooked simulators whose workgroups share one copy of a world's state
+    (a large layout that does not fit one tile, with fewer than 8192 worlds: ``mrl_overcooked_step_team``) step alone."""
+    return type(sim) is OvercookedSimulator and "step_team" not in sim.kernel_name
+
+
 def step_many(sims, actions=None):
     """One launch for several ``OvercookedSimulator``s on one GPU -- any mix of layouts and world counts (``mrl_step_many``).
     ``actions``: None (every simulator's ACTION tensor) or one int32 tensor per simulator (an entry may be None)."""

@@ -316,6 +316,36 @@ def test_several_layouts_as_one_batch(mode, hip_lib):
         env.close()
 
 
+@pytest.mark.parametrize("mode", ["auto", "one_launch"])
+def test_several_layouts_with_one_that_steps_alone(mode, hip_lib):
+    """A large layout at a small world count runs the kernel whose workgroups share one copy of a world, which mrl_step_many
+    does not take: the default mode must still step such a batch -- the others in one launch, that one by its own
+    call -- and ten small layouts are two launches of at most eight."""
+    from madrona_rl_envs_playground_amd.envs import OvercookedMadrona
+    from madrona_rl_envs_playground_amd.envs.multi_layout import OvercookedMultiLayout
+    from madrona_rl_envs_playground_amd.simulators import can_step_with_others
+    names = ["cramped_room", "many_player_layout", "coordination_ring"] + ["cramped_room", "forced_coordination"] * 4
+    counts = [200, 500, 130] + [33, 65] * 4
+    multi = OvercookedMultiLayout(names, counts, 0, horizon=30, num_players=4, mode=mode)
+    players = [env.num_players for env in multi.envs]
+    assert players[1] == 4 and players[0] == 2
+    assert multi.mode == "one_launch" and multi._alone == [1] and [len(g) for g in multi._shared] == [8, 2]
+    assert not can_step_with_others(multi.envs[1].sim) and multi.envs[1].sim.kernel_name.startswith("mrl_overcooked_step_team")
+    singles = [OvercookedMadrona(name, n, 0, horizon=30, num_players=4) for name, n in zip(names, counts)]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(45):
+        dtype = torch.int32 if t % 2 else torch.int64
+        acts = [torch.randint(0, 6, (p, n, 1), device="cuda", generator=gen, dtype=dtype) for p, n in zip(players, counts)]
+        got = multi.n_step(acts)
+        for k, env in enumerate(singles):
+            obs, rew, done, _ = env.n_step(acts[k])
+            assert all(torch.equal(a.obs, b.obs) for a, b in zip(obs, got[k][0])), names[k]
+            assert torch.equal(rew, got[k][1]) and torch.equal(done, got[k][2])
+    multi.close()
+    for env in singles:
+        env.close()
+
+
 def test_one_launch_for_several_simulators_of_any_shape(hip_lib, oracle_lib):
     """mrl_step_many: eight simulators -- different layouts, player counts (2, 3, 4), world counts from 5 to 4099, horizons --
     stepped by one launch per step, each against its own oracle; bad lists are refused."""

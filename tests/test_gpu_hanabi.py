@@ -30,8 +30,10 @@ def legal_random(rng, mask):
 def compare(sim, orc, tag, cfg):
     # compared on the windows the reference wrapper exposes (envs/hanabi_env.py:92-104:
     # [:obs_size], [:state_size]); bytes past them are leftovers of longer encodings in the
-    # reference (see oracle/hanabi_oracle.c) and zero here
+    # reference (see oracle/hanabi_oracle.c).  The OBSERVATION tensor is exactly obs_size wide: it is a view of
+    # the state row, which goes on with the agent's own hand -- not for the observer
     no, ns = hanabi_spec.observation_size(cfg), hanabi_spec.state_size(cfg)
+    assert sim.observation_tensor().to_torch().shape[-1] == no
     got_o = sim.observation_tensor().to_torch().cpu().numpy().astype(np.uint8)
     got_s = sim.agent_state_tensor().to_torch().cpu().numpy().astype(np.uint8)
     assert np.array_equal(got_o[..., :no], orc.obs[..., :no]), f"obs {tag}"
@@ -48,7 +50,7 @@ def compare(sim, orc, tag, cfg):
 def test_lockstep_vs_oracle(cfg, n, steps, hip_lib, oracle_lib):
     sim, orc = make(cfg, n), oracle_lib.HanabiOracle(cfg, n, num_threads=8)
     obs = sim.observation_tensor().to_torch()
-    assert obs.shape == (2, n, 658) and obs.dtype == torch.int8
+    assert obs.shape == (2, n, hanabi_spec.observation_size(cfg)) and obs.dtype == torch.int8
     assert sim.agent_state_tensor().to_torch().shape == (2, n, 783)
     assert sim.action_mask_tensor().to_torch().shape == (2, n, 20)
     assert sim.reward_tensor().to_torch().dtype == torch.float32

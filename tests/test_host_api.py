@@ -165,3 +165,73 @@ def test_random_policy_host_restatements():
     # uniform over the legal moves: position among the legal ones is uniform
     rank = (np.cumsum(legal, -1) - 1)[w[ok], act[ok]] / legal.sum(-1)[ok]
     assert abs(rank.mean() - (0.5 - (0.5 / legal.sum(-1)[ok]).mean())) < 0.02
+
+
+class TurnTaker:
+    """A single-world two-player environment in the reference's MultiAgentEnv protocol
+    (pantheonrl_extension/multiagentenv.py:236-276): players alternate, an episode lasts `length` moves, the observation is
+    (move counter, mover), the reward of both players is the action taken."""
+    n_players = 2
+    observation_space = spaces.MultiBinary(2)
+    share_observation_space = spaces.MultiBinary(3)
+    action_space = spaces.Discrete(4)
+
+    def __init__(self, length, offset):
+        self.length, self.offset, self.t, self.episodes, self.log = length, offset, 0, 0, []
+
+    def _view(self):
+        mover = (self.t + self.offset) % 2
+        obs = np.array([self.t, mover], np.float32)
+        return (mover,), ((obs, np.array([self.t, mover, self.episodes], np.float32), np.array([1, 1, mover, 1], bool)),)
+
+    def n_reset(self):
+        self.t = 0
+        self.episodes += 1
+        return self._view()
+
+    def n_step(self, actions):
+        assert len(actions) == 1
+        self.log.append(int(np.asarray(actions[0]).reshape(-1)[0]))
+        self.t += 1
+        agents, obs = self._view()
+        rew = float(self.log[-1])
+        return agents, obs, (rew, rew), self.t >= self.length, {"t": self.t}
+
+
+def test_sync_vector_env_steps_python_envs_one_by_one():
+    """SyncVectorEnv (reference vectorenv.py:348-457): per-world resets inside n_step, inactive players keep their rows,
+    only the acting player's action reaches an environment."""
+    from madrona_rl_envs_playground_amd.pantheonrl_extension import SyncVectorEnv
+    lengths = [3, 5, 2]
+    env = SyncVectorEnv([lambda k=k, n=n: TurnTaker(n, k) for k, n in enumerate(lengths)], device=torch.device("cpu"))
+    assert env.num_envs == 3 and env.n_players == 2 and env.action_space.n == 4
+    obs = env.n_reset()
+    assert len(obs) == 2 and obs[0].obs.shape == (3, 2) and obs[0].state.shape == (3, 3) and obs[0].action_mask.shape == (3, 4)
+    assert obs[0].active.tolist() == [True, False, True] and obs[1].active.tolist() == [False, True, False]
+    rng = np.random.default_rng(0)
+    t = [0, 0, 0]
+    for step in range(12):
+        acts = torch.from_numpy(rng.integers(0, 4, size=(2, 3, 1)))
+        movers = [int(obs[1].active[w]) for w in range(3)]
+        obs, rew, done, infos = env.n_step(acts)
+        for w in range(3):
+            took = int(acts[movers[w], w, 0])
+            assert env.envs[w].log[-1] == took                                   # the mover's action, nobody else's
+            assert rew[:, w].tolist() == [took, took]
+            t[w] += 1
+            ended = t[w] >= lengths[w]
+            assert bool(done[w]) == ended and infos[w]["t"] == t[w]
+            if ended:
+                t[w] = 0                                                         # the next episode's first observation
+            mover = (t[w] + w) % 2
+            assert obs[mover].active[w] and not obs[1 - mover].active[w]
+            assert obs[mover].obs[w].tolist() == [t[w], mover]
+            assert obs[mover].action_mask[w].tolist() == [True, True, bool(mover), True]
+    assert [e.episodes for e in env.envs] == [1 + 12 // n for n in lengths]
+    # the ego-perspective step on top of it
+    env.add_partner_agent(RandomVectorAgent(lambda: torch.zeros((3, 1), dtype=torch.int64)))
+    ego = env.reset()
+    assert ego.obs.shape == (3, 2)
+    ob, r, d, info = env.step(torch.ones((3, 1), dtype=torch.int64))
+    assert ob.obs.shape == (3, 2) and r.shape == (3,) and d.shape == (3,)
+    env.close()
