@@ -351,12 +351,18 @@ int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t 
  * its observation slab -- int8 (N, P, H, W, F), the OBS_WORLD_MAJOR layout, `bytes` = N*P*H*W*F -- to obs_dev_or_null
  * and leaves the OBSERVATION / OBS_WORLD_MAJOR tensors untouched; NULL hands the output back to them.  Same bytes, same
  * stores, no copy: the kernels take the slab's address from their launch arguments and never read it back.  The
- * buffer must be 16-byte aligned and stay valid until the work enqueued before the next call of this function has
- * finished.  Overcooked and Simplecooked (MRL_ERR_INVALID for the other games).  Host-only call: nothing is enqueued. */
+ * buffer must stay valid until the work enqueued before the next call of this function has finished.  A buffer that
+ * starts on a 16-byte boundary costs nothing; one that does not (slot k of a dense (T, N, P, H, W, F) buffer whose
+ * N*P*H*W*F is not a multiple of 16) is accepted too and STAGED: the kernels stream 16-byte chunks from an aligned base,
+ * so the step writes a slab of the simulator's own (allocated at the first such call; the exported tensors stay
+ * untouched) and one device-to-device copy behind the launch, on the same stream, moves it to the slot -- one more
+ * pass over the slab per step.  Overcooked and Simplecooked (MRL_ERR_INVALID for the other games).  Host-only call
+ * (but for that allocation): nothing is enqueued. */
 int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t bytes);
 
-/* The same for a whole rollout buffer: a ring of num_slots observation slots, slot s at base + s * slot_stride_bytes (a
- * multiple of 16, >= N*P*H*W*F).  Step number k counted from this call -- whether it is a launch of its own or step k of a
+/* The same for a whole rollout buffer: a ring of num_slots observation slots, slot s at base + s * slot_stride_bytes
+ * (>= N*P*H*W*F; with base and stride multiples of 16 the slots are written in place, otherwise they are staged as
+ * above and the multi-step launches run one launch + one copy per step).  Step number k counted from this call -- whether it is a launch of its own or step k of a
  * multi-step launch (mrl_rollout_random, mrl_step_sequence: the kernel moves on to the next slot itself) -- writes its
  * observations to slot k % num_slots.  One mrl_rollout_random(sim, T, ...) then fills a T-slot buffer with T steps of
  * random-policy experience in one launch.  base == NULL hands the output back to the simulator's own tensor; one slot is

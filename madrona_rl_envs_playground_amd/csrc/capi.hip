@@ -318,8 +318,8 @@ int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t byt
         mrl::set_error("mrl_set_observation_output: game %d writes no redirectable observation slab (Overcooked and Simplecooked do)", sim->game);
         return MRL_ERR_INVALID;
     }
-    if (obs_dev_or_null && (bytes != want || (reinterpret_cast<uintptr_t>(obs_dev_or_null) & 15u))) {
-        mrl::set_error("mrl_set_observation_output: need a 16-byte aligned device buffer of exactly %llu bytes (N x P x H x W x F int8), got %llu at %p",
+    if (obs_dev_or_null && bytes != want) {
+        mrl::set_error("mrl_set_observation_output: need a device buffer of exactly %llu bytes (N x P x H x W x F int8), got %llu at %p",
                        (unsigned long long)want, (unsigned long long)bytes, obs_dev_or_null);
         return MRL_ERR_INVALID;
     }
@@ -334,9 +334,9 @@ int mrl_set_observation_ring(mrl_sim *sim, void *base_dev_or_null, uint64_t slot
         mrl::set_error("mrl_set_observation_ring: game %d writes no redirectable observation slab (Overcooked and Simplecooked do)", sim->game);
         return MRL_ERR_INVALID;
     }
-    if (base_dev_or_null && (num_slots == 0 || slot_stride_bytes < want || (slot_stride_bytes & 15u) || (reinterpret_cast<uintptr_t>(base_dev_or_null) & 15u))) {
-        mrl::set_error("mrl_set_observation_ring: need a 16-byte aligned device buffer, at least one slot and a slot stride that is a multiple "
-                       "of 16 and >= %llu bytes (N x P x H x W x F int8); got stride %llu, %u slot(s) at %p",
+    if (base_dev_or_null && (num_slots == 0 || slot_stride_bytes < want)) {
+        mrl::set_error("mrl_set_observation_ring: need at least one slot and a slot stride >= %llu bytes (N x P x H x W x F int8); got stride "
+                       "%llu, %u slot(s) at %p",
                        (unsigned long long)want, (unsigned long long)slot_stride_bytes, num_slots, base_dev_or_null);
         return MRL_ERR_INVALID;
     }

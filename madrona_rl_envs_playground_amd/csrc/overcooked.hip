@@ -2063,18 +2063,32 @@ struct OvercookedSim final : mrl_sim {
     uint64_t ring_stride = 0;
     uint32_t ring_slots = 1;
     uint64_t ring_pos = 0;
+    // Slots that do not start on 16-byte boundaries (a dense (T, N, P, H, W, F) buffer whose N x P x H x W x F is not a
+    // multiple of 16: coordination_ring at 1001 worlds) are STAGED: the kernels stream a slab out in 16-byte chunks from a
+    // 16-byte aligned base, so the step writes a slab of the simulator's (`staging`, allocated at the first such call; the
+    // exported tensor stays untouched) and a device-to-device copy behind the launch moves it to the slot -- one more pass
+    // over the slab per step, and the multi-step launches run one launch per step.  Aligned slots cost nothing.
+    bool staged = false;
+    uint8_t *staging = nullptr, *pending_dest = nullptr;
     void set_observation_ring(void *base, uint64_t stride_bytes, uint32_t slots) override
     {
         ring_base = base ? static_cast<uint8_t *>(base) : own_obs;
         ring_stride = base ? stride_bytes : 0;
         ring_slots = base && slots > 1 ? slots : 1;
         ring_pos = 0;
+        staged = base && ((reinterpret_cast<uintptr_t>(base) & 15u) != 0 || (ring_slots > 1 && (ring_stride & 15u) != 0));
+        if (staged && !staging) staging = arena.alloc<uint8_t>(observation_bytes(), false);
         for (StepParams *q : {&params, &wide_params}) {
-            q->obs = ring_base;
-            q->ring_stride = ring_stride;
-            q->ring_slots = ring_slots;
+            q->obs = staged ? staging : ring_base;
+            q->ring_stride = staged ? 0 : ring_stride;
+            q->ring_slots = staged ? 1 : ring_slots;
             q->ring_first = 0;
         }
+    }
+    // staged slots: the slab just written -> the caller's slot, behind the launch on the same stream
+    void deliver(uint8_t *dest, hipStream_t stream)
+    {
+        if (staged && dest) MRL_HIP(hipMemcpyAsync(dest, staging, observation_bytes(), hipMemcpyDeviceToDevice, stream));
     }
     // the slot(s) of the next `steps` steps: single-step launches get the slot as their `obs`, multi-step ones the first index
     uint8_t *take_slots(uint32_t steps, uint32_t *first)
@@ -2090,7 +2104,8 @@ struct OvercookedSim final : mrl_sim {
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
-        a.obs = take_slots(1, nullptr);
+        pending_dest = take_slots(1, nullptr);  // (staged: delivered by step_many_overcooked behind the shared launch)
+        a.obs = staged ? staging : pending_dest;
         a.ring_slots = 1;
         a.per_xcd = grid >> 3;
         a.pair_exchange = (a.P == 2 && !generic) ? 1u : 0u;
@@ -2101,7 +2116,8 @@ struct OvercookedSim final : mrl_sim {
     {
         StepParams a = params;
         a.actions = actions ? actions : action;
-        if (!init) a.obs = take_slots(1, nullptr);
+        uint8_t *const dest = init ? nullptr : take_slots(1, nullptr);
+        if (!init) a.obs = staged ? staging : dest;
         a.ring_slots = 1;  // a single step writes exactly its `obs`
         a.per_xcd = ((!init && groups_kernel) ? groups_grid : grid) >> 3;
         const void *hot_actions = a.actions64 ? static_cast<const void *>(a.actions64) : static_cast<const void *>(a.actions);
@@ -2121,6 +2137,7 @@ struct OvercookedSim final : mrl_sim {
         else
             hipLaunchKernelGGL(generic_step, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         MRL_HIP(hipGetLastError());
+        deliver(dest, stream);
     }
 
     void phase1(const int32_t *actions, hipStream_t stream) override { launch(false, actions, stream); }
@@ -2138,7 +2155,7 @@ struct OvercookedSim final : mrl_sim {
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
         if (num_steps == 0) return;
-        if (params.whole) {
+        if (params.whole && !staged) {
             take_slots(num_steps, &params.ring_first);
             wide_params.ring_first = params.ring_first;
             if (wide_rollout)
@@ -2164,7 +2181,7 @@ struct OvercookedSim final : mrl_sim {
     void step_sequence(const int32_t *actions, uint32_t num_steps, hipStream_t stream) override
     {
         if (num_steps == 0) return;
-        if (params.whole) {
+        if (params.whole && !staged) {
             take_slots(num_steps, &params.ring_first);
             wide_params.ring_first = params.ring_first;
             if (wide_rollout)
@@ -2713,4 +2730,8 @@ void mrl::step_many_overcooked(mrl_sim *const *sims, uint32_t count, const int32
         MRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mrl_overcooked_step_many), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mrl_overcooked_step_many, dim3(blocks), dim3(kBlock), lds, stream, m);
     MRL_HIP(hipGetLastError());
+    for (uint32_t k = 0; k < count; k++) {
+        auto *sim = static_cast<OvercookedSim *>(sims[k]);
+        sim->deliver(sim->pending_dest, stream);  // (simulators whose slots are staged: OvercookedSim::set_observation_ring)
+    }
 }

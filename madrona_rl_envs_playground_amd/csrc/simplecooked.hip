@@ -844,11 +844,16 @@ struct SimplecookedSim final : mrl_sim {
         ring_stride = base ? stride_bytes : 0;
         ring_slots = base && slots > 1 ? slots : 1;
         ring_pos = 0;
-        params.obs = ring_base;
-        params.ring_stride = ring_stride;
-        params.ring_slots = ring_slots;
+        // slots off 16-byte boundaries are staged (OvercookedSim::set_observation_ring): a slab of the simulator's + one copy
+        staged = base && ((reinterpret_cast<uintptr_t>(base) & 15u) != 0 || (ring_slots > 1 && (ring_stride & 15u) != 0));
+        if (staged && !staging) staging = arena.alloc<uint8_t>(observation_bytes(), false);
+        params.obs = staged ? staging : ring_base;
+        params.ring_stride = staged ? 0 : ring_stride;
+        params.ring_slots = staged ? 1 : ring_slots;
         params.ring_first = 0;
     }
+    bool staged = false;
+    uint8_t *staging = nullptr;
     uint8_t *take_slots(uint32_t steps, uint32_t *first)
     {
         const uint32_t at = (uint32_t)(ring_pos % ring_slots);
@@ -869,7 +874,8 @@ struct SimplecookedSim final : mrl_sim {
     void launch(bool init, const SimpleParams &given, hipStream_t stream)
     {
         SimpleParams a = given;
-        if (!init) a.obs = take_slots(1, nullptr);
+        uint8_t *const dest = init ? nullptr : take_slots(1, nullptr);
+        if (!init) a.obs = staged ? staging : dest;
         a.ring_slots = 1;  // a single step writes exactly its `obs`
         if (init) {
             if (a.P == 2)
@@ -885,6 +891,7 @@ struct SimplecookedSim final : mrl_sim {
             hipLaunchKernelGGL(generic_step, dim3(grid), dim3(kBlock), lds_bytes, stream, a);
         }
         MRL_HIP(hipGetLastError());
+        if (staged && dest) MRL_HIP(hipMemcpyAsync(dest, staging, observation_bytes(), hipMemcpyDeviceToDevice, stream));
     }
 
     void phase1(const int32_t *actions, hipStream_t stream) override
@@ -907,7 +914,7 @@ struct SimplecookedSim final : mrl_sim {
     // all steps of a call in one launch (two players, flat tile; see rollout_body)
     bool launch_rollout(uint32_t num_steps, uint64_t seed, uint32_t first_step, const int32_t *action_seq, hipStream_t stream)
     {
-        if (params.P != 2 || !params.flat) return false;
+        if (params.P != 2 || !params.flat || staged) return false;  // (staged slots: one launch + one copy per step)
         SimpleParams a = params;
         a.action_out = action;
         take_slots(num_steps, &a.ring_first);

@@ -546,7 +546,8 @@ def test_random_layouts_against_oracle(seed, hip_lib, oracle_lib):
     sim.close()
 
 
-@pytest.mark.parametrize("layout,n", [("cramped_room", 4099), ("coordination_ring", 1004), ("counter_circuit", 33000)])  # slots must start on 16-byte boundaries: N x block bytes a multiple of 16
+@pytest.mark.parametrize("layout,n", [("cramped_room", 4099), ("coordination_ring", 1001), ("counter_circuit", 33000),
+                                      ("forced_coordination", 33001)])  # 1001 / 33001 worlds x 1300 bytes: slots 1..4 of the dense ring start off 16-byte boundaries (staged)
 def test_steps_into_a_ring_of_caller_slots_equal_steps_plus_clones(layout, n, hip_lib, oracle_lib):
     """mrl_set_observation_output (the rollout-buffer side): K steps whose observations the
     kernel writes into slot k % T of a caller's ring equal K ordinary steps each followed by a clone (what the reference's
@@ -586,23 +587,31 @@ def test_steps_into_a_ring_of_caller_slots_equal_steps_plus_clones(layout, n, hi
     into.step_with_actions(a)
     plain.step_with_actions(a)
     assert torch.equal(own, plain.observation_world_major_tensor().to_torch())
-    # validation: wrong size / dtype / alignment are refused
+    # validation: wrong size / dtype / device are refused
     with pytest.raises(Exception):
         into.set_observation_output(ring[0].flatten()[:-16])
     with pytest.raises(ValueError):
         into.set_observation_output(ring[0].to(torch.int32))
     with pytest.raises(ValueError):
         into.set_observation_output(ring[0].cpu())
-    if own.numel() % 16 == 0:
-        odd = torch.zeros(own.numel() + 16, dtype=torch.int8, device="cuda")[3:3 + own.numel()]
-        with pytest.raises(Exception, match="aligned"):
-            into.set_observation_output(odd)
+    # a slot at ANY byte offset is taken (off 16-byte boundaries it is staged: a slab of the simulator's + one device copy)
+    for off in (1, 3, 8, 13):
+        odd = torch.zeros(own.numel() + 16, dtype=torch.int8, device="cuda")
+        slot = odd[off:off + own.numel()].view(own.shape)
+        assert slot.data_ptr() % 16 == (odd.data_ptr() + off) % 16 != 0
+        into.set_observation_output(slot)
+        a = torch.randint(0, 6, (P, n, 1), dtype=torch.int32, device="cuda", generator=gen)
+        into.step_with_actions(a)
+        plain.step_with_actions(a)
+        assert torch.equal(slot, plain.observation_world_major_tensor().to_torch()), f"slot at offset {off}"
+        assert not odd[:off].any() and not odd[off + own.numel():].any(), "bytes around the slot were written"
     into.close()
     plain.close()
 
 
-@pytest.mark.parametrize("layout,n", [("cramped_room", 4100), ("counter_circuit", 1000), ("multiplayer_schelling", 128), ("coordination_ring", 33000)])
-def test_multi_step_launches_fill_a_ring_of_slots(layout, n, hip_lib):
+@pytest.mark.parametrize("layout,n,dense", [("cramped_room", 4100, False), ("counter_circuit", 1000, False), ("multiplayer_schelling", 128, False),
+                                            ("coordination_ring", 33000, False), ("coordination_ring", 1001, True), ("asymmetric_advantages", 4099, True)])
+def test_multi_step_launches_fill_a_ring_of_slots(layout, n, dense, hip_lib):
     """mrl_set_observation_ring: step k from the call on writes its observations to slot k % T of the caller's buffer -- inside
     ONE multi-step launch (mrl_rollout_random, mrl_step_sequence: the kernel moves from slot to slot itself), across launches,
     and for single steps.  Every slot must hold exactly what a twin simulator, stepped one launch at a time, shows after that step."""
@@ -612,7 +621,10 @@ def test_multi_step_launches_fill_a_ring_of_slots(layout, n, hip_lib):
     own = ringed.observation_world_major_tensor().to_torch()
     before = own.clone()
     T = 6
-    slot_bytes = (own.numel() + 15) // 16 * 16  # slots start on 16-byte boundaries whatever N
+    # padded: slots start on 16-byte boundaries whatever N, written in place; dense: a plain (T, N, P, H, W, F) buffer, whose
+    # slots then start wherever N x block bytes puts them (staged: one launch + one device copy per step)
+    slot_bytes = own.numel() if dense else (own.numel() + 15) // 16 * 16
+    assert not dense or slot_bytes % 16 != 0
     store = torch.zeros(T * slot_bytes, dtype=torch.int8, device="cuda")
     ring = torch.as_strided(store, (T,) + tuple(own.shape), (slot_bytes,) + tuple(own.stride()))
     ringed.set_observation_ring(ring)

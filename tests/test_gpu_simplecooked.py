@@ -359,7 +359,7 @@ def test_env_steps_into_a_callers_slot(hip_lib, oracle_lib):
     observations into the caller's (N, P, H, W, F) slot, the observations handed out are views of it and equal the oracle;
     without `out` the next step goes back to the simulator's own tensor."""
     from madrona_rl_envs_playground_amd.envs.overcooked2_env import OvercookedMadrona
-    n = 3002  # slots must start on 16-byte boundaries: N x 1800 bytes a multiple of 16
+    n = 3001  # N x 1800 bytes is not a multiple of 16: slots 1 and 2 of the dense ring are staged (a slab of the simulator's + one copy)
     env = OvercookedMadrona("unident_s", n, 0, horizon=30)
     params = layouts.get_simplecooked_layout_params("unident_s", 30)
     orc = oracle_lib.SimplecookedOracle(params, n, num_threads=8)
