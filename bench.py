@@ -36,7 +36,12 @@ and `isolated_with_copies` (scripts/overcooked_isolated_example.py:56-65), and `
 BASELINE.json configurations one GPU can run -- Cartpole 1024 worlds (configs[0]) and 1 M worlds, Hanabi
 65536 worlds (configs[2]: scripts/hanabi_example.py:62-80), the four other standard layouts at the 32768-world
 shard of configs[3], and the two sibling worlds (Simplecooked `simple` 32768 worlds, balance beam 1 M worlds) -- each with
-its kernel, average launch duration over >= 300 launches, algorithmic bytes per world-step and roofline fraction.
+its kernel, average launch duration over >= 300 launches, algorithmic bytes per world-step and roofline fraction; the Hanabi
+and the 1 M-world Cartpole legs carry a `cpu_baseline` of their own (the oracle, ~2 s); `mappo_rollout_loop_32768` is
+configs[4] on one GPU (50 loop steps of tools/mappo_rollout_loop.py: the PyTorch policy's loop time and, beside it, what this
+engine owns of a loop step: `env_step_plus_buffer_insert_us`).  `build_hash` = `mrl_build_hash()` of the running library.
+With N > 1 the line also carries `expected` (and `obs_gather.expected`): what DESIGN.md section 6 predicted before any
+multi-GPU run existed.
 
 `roofline.traffic` (and `traffic` of the other legs) are HBM bytes per launch from rocprofv3 PMC passes, which
 cannot run inside this process: they come from profiles/step_traffic.json and are quoted only when that file's
@@ -131,6 +136,103 @@ def cpu_baseline(params, seconds):
             "sample": f"{steps} steps x {n} worlds of the same workload ({dt:.1f} s, OpenMP over worlds)"}
 
 
+def cpu_baseline_game(game, n, seconds=2.0):
+    """The TEST-ONLY oracle of Hanabi / Cartpole timed like `cpu_baseline` (kind 'port'): the leg's world count, the leg's
+    policy (masked-random legal moves / uniform random pushes), the host cores available to this job, ~`seconds` of work
+    (the reference quotes its CPU figures beside the GPU's: src/hanabi_env/README.org:77-81, src/cartpole_env/README.org:80-85)."""
+    import numpy as np
+    from oracle import oracle
+    cores = min(host_cores(), 64)
+    rng = np.random.default_rng(0)
+    if game == "hanabi":
+        orc = oracle.HanabiOracle(dict(colors=5, ranks=5, players=2, max_information_tokens=8, max_life_tokens=3), n, num_threads=cores)
+
+        def one():  # scripts/hanabi_example.py:64-67: argmax(rand * mask) of each agent's current mask
+            orc.step((rng.random(orc.mask.shape, dtype=np.float32) * (orc.mask != 0)).argmax(-1).astype(np.int32))
+    else:
+        orc = oracle.CartpoleOracle(n, num_threads=cores)
+        acts = [rng.integers(0, 2, size=(n, 1)).astype(np.int32) for _ in range(8)]
+        count = [0]
+
+        def one():
+            orc.step(acts[count[0] % 8])
+            count[0] += 1
+    one()
+    steps, in_oracle, t0 = 0, 0.0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        one()
+        steps += 1
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x {n} worlds ({dt:.1f} s, OpenMP over worlds"
+                      + (", the numpy sampling of the legal moves included)" if game == "hanabi" else ")")}
+
+
+def mappo_leg(args, torch, local_rank):
+    """configs[4] on one GPU: the loop of train/MAPPO/main_player.py:211-261 (tools/mappo_rollout_loop.py: fp32 torch CNN actor +
+    critic for ego and partner, env.step, buffer insert) at the headline's batch.  The policy is PyTorch and out of this
+    engine's scope; what this engine owns is `env_step_plus_buffer_insert_us`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mappo_rollout_loop", os.path.join(REPO, "tools", "mappo_rollout_loop.py"))
+    loop = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loop)
+    n, T, steps = args.worlds, 16, 50
+    out = {"workload": f"MAPPO-style rollout loop, {args.layout}, {n} worlds", "steps": steps}
+    for in_place in (True, False):
+        env, ego, buffers = loop.build(args.layout, n, gpu_id=local_rank, horizon=args.horizon, steps_in_buffer=T, seed=0, in_place=in_place)
+        ob = loop.rollout(env, ego, buffers, env.reset(), 5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ob = loop.rollout(env, ego, buffers, ob, steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        key = "step_into_slot" if in_place else "step_then_clone_insert"
+        out.setdefault("loop_ms_per_step", {})[key] = ms
+        out.setdefault("loop_env_steps_per_s", {})[key] = n / (ms * 1e-3)
+        if in_place:
+            rand = torch.randint(0, 6, (env.num_players, n, 1), device="cuda")
+            ring = buffers["obs"]
+            copies = torch.empty((8, n, env.width, env.height, 5 * env.num_players + 16), dtype=torch.int8, device="cuda")
+
+            def timed(fn, reps=200):
+                for i in range(10):
+                    fn(i)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for i in range(reps):
+                    fn(i)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / reps * 1e6
+            out["env_step_plus_buffer_insert_us"] = {
+                "step_into_slot": timed(lambda i: env.n_step(rand, out=ring[i % T])),
+                "step_then_clone_insert": timed(lambda i: copies[i % 8].copy_(env.n_step(rand)[0][env.ego_ind].obs))}
+            env.n_step(rand)
+            del copies
+        env.close()
+        del buffers
+    own = out["env_step_plus_buffer_insert_us"]["step_into_slot"]
+    out["policy_share_of_loop"] = 1.0 - own * 1e-3 / out["loop_ms_per_step"]["step_into_slot"]
+    out["note"] = ("loop_* is the PyTorch policy's number (fp32 CNN forward for ego and partner: ~99 % of a loop step); this engine's piece "
+                   "is env_step_plus_buffer_insert_us -- the step writing its observations into the buffer slot against step + clone-insert")
+    return out
+
+
+def expected_gather(shard_bytes, world_size, step_seconds):
+    """What the obs_gather leg should show on an 8-GPU MI355X node, written down BEFORE the first multi-GPU run (DESIGN.md
+    section 6): every rank receives (G - 1) shards over its xGMI links (7 links per GPU, ~153 GB/s each by SURVEY.md section 5's
+    figure, point to point).  Upper bound on the bus bandwidth: all G - 1 peers' links streaming at the link rate; lower: RCCL's
+    ring (one link's worth, ~60 % efficient).  `gather_ms_per_step` follows from bytes / busbw."""
+    peers = world_size - 1
+    recv = shard_bytes * peers
+    hi = peers * 153.0          # direct all-gather, every peer on its own link at the link rate
+    lo = 0.6 * 153.0            # ring: one link's rate at RCCL's usual efficiency
+    ms = [recv / (bw * 1e9) * 1e3 for bw in (hi, lo)]
+    return {"busbw_GBps": [lo, hi], "gather_ms_per_step": ms,
+            "value": [world_size * 32768 / (step_seconds + m * 1e-3) for m in reversed(ms)],
+            "basis": "bytes received per rank = shard x (G - 1); busbw between one xGMI link at 60 % (ring) and G - 1 links at 153 GB/s (direct)"}
+
+
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` on `workload` from the committed PMC passes -- only if they were taken on THIS build
     of the kernels (tools/pmc_traffic.py writes the file together with the hash of csrc/)."""
@@ -190,6 +292,8 @@ def other_configs(args, torch, local_rank, launches_us):
                                    note="kernel_us_avg = time per step call back to back; at 1024 worlds that is the host's call rate, not the kernel" if n == 1024 else None)
         sim.close()
         del pool
+        if n > 1024 and not args.no_cpu_baseline:
+            out[f"cartpole_{n}"]["cpu_baseline"] = cpu_baseline_game("cartpole", n)
 
     # the sibling worlds: Simplecooked (overcooked2_env, what the reference's trainers use) on its
     # `simple` layout at the 32768-world shard, the balance beam at 1 M worlds
@@ -246,7 +350,11 @@ def other_configs(args, torch, local_rank, launches_us):
     h["persistent_rollout_us_per_step"] = launches_us(lambda i: sim.rollout_random(300, seed=7, first_step=50 + 300 * i), 2) / 300
     h["rollout_kernel"] = sim.rollout_kernel_name  # (the step kernel's name here = the runtime refused the cooperative launch)
     sim.close()
+    if not args.no_cpu_baseline:
+        h["cpu_baseline"] = cpu_baseline_game("hanabi", n)
     out[f"hanabi_{n}"] = h
+    # configs[4]: the MAPPO rollout inner loop at the headline's batch
+    out[f"mappo_rollout_loop_{args.worlds}"] = mappo_leg(args, torch, local_rank)
     return out
 
 
@@ -557,12 +665,17 @@ def run(args):
             "timing": {"blocks": len(blocks), "block_ms": [b * 1e3 for b in blocks], "reported": "median block", "empty_block_ms": empty_block_ms,
                        "per_rank_ms_per_step": per_rank_ms, "rank_min_ms_per_step": min(per_rank_ms), "rank_max_ms_per_step": max(per_rank_ms)},
             "roofline": roofline,
+            "build_hash": _lib.build_hash(),  # mrl_build_hash(): the sources the running library was compiled from; `traffic` is keyed by it
         }
         if use_dist:
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend,
                             "rehearsal_on_one_gpu": bool(rehearse)}
             if gather is not None:
+                gather["expected"] = expected_gather(obs.numel(), world_size, dt / args.steps)
                 out["obs_gather"] = gather
+            out["expected"] = {"value": [world_size * n / (x * 1e-3) for x in (9.0e-3, 8.0e-3)], "unit": "env-steps/s",
+                               "basis": "no collective in the step: G x the single-GPU rate (8.0-9.0 us per step measured at N = 1, "
+                                        "BENCH_r03 / profiles/r04_*), within the per-rank spread; DESIGN.md section 6"}
         out.update(extras)
         if not args.no_cpu_baseline and solo:
             out["cpu_baseline"] = cpu_baseline(params, args.cpu_seconds)

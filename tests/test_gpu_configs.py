@@ -190,10 +190,19 @@ def test_bench_line_carries_every_single_gpu_config(hip_lib):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["roofline"]["bound"] == "hbm" and out["cpu_baseline"]["kind"] == "port"
+    assert out["build_hash"] == _lib.build_hash() == _lib.source_hash()
     legs = out["other_configs"]
     want = ([f"overcooked_{name}_32768" for name in STANDARD[1:]] + ["cartpole_1024", "cartpole_1048576", "hanabi_65536"] +
             ["simplecooked_simple_32768", "balance_beam_1048576"])  # (the two sibling worlds of SURVEY section 8(f)-4)
+    mappo = legs.pop("mappo_rollout_loop_32768")  # configs[4] on one GPU: the policy's number, and this engine's piece of it
     assert sorted(legs) == sorted(want)
+    assert mappo["steps"] == 50 and 0.5 < mappo["policy_share_of_loop"] < 1.0
+    assert set(mappo["loop_ms_per_step"]) == set(mappo["env_step_plus_buffer_insert_us"]) == {"step_into_slot", "step_then_clone_insert"}
+    assert mappo["env_step_plus_buffer_insert_us"]["step_into_slot"] < mappo["env_step_plus_buffer_insert_us"]["step_then_clone_insert"]
+    for name in ("hanabi_65536", "cartpole_1048576"):  # the reference quotes its CPU figures beside the GPU's
+        cpu = legs[name]["cpu_baseline"]
+        assert cpu["kind"] == "port" and cpu["cores"] >= 1 and 0 < cpu["value"] < legs[name]["value"]
+    assert legs["cartpole_1048576"]["kernel"] == "mrl_cartpole_step_fused"
     for name, leg in legs.items():
         assert leg["launches_timed"] >= 300 and leg["kernel_us_avg"] > 0 and leg["value"] > 0 and leg["kernel"].startswith("mrl_"), name
         assert abs(leg["frac"] - leg["bytes_per_world_step"] * leg["worlds"] / (leg["kernel_us_avg"] * 1e-6) / 8e12) < 1e-9
