@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MRL_ABI_VERSION 3
+#define MRL_ABI_VERSION 4
 
 /* return codes */
 enum {
@@ -343,6 +343,24 @@ int mrl_step_phase2(mrl_sim *sim, const uint32_t *episode_base_dev, void *hip_st
  * phase 1 -> all-gather of one word per rank -> this call, with no other device work in between and no host
  * sync.  The counter must have been set by mrl_reseed_shard.  No-op for games without an episode counter. */
 int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t num_ranks, uint32_t rank, void *hip_stream);
+
+/* The same exchange WITHOUT a collective (round 4): a device-side mailbox.  Every rank owns a small block of device memory;
+ * mrl_exchange_create allocates it for this rank of `num_ranks` (<= MRL_MAX_RANKS) and returns its IPC handle
+ * (MRL_IPC_HANDLE_BYTES bytes, hipIpcGetMemHandle); the caller gives every rank the handles of all ranks, in rank order (one
+ * all-gather of 64 bytes at set-up), and mrl_exchange_connect maps the peers' blocks (hipIpcOpenMemHandle).  From then on
+ *     mrl_step_exchanged(sim, actions_or_null, stream)
+ * is one whole step of the shard: phase 1; a one-workgroup launch that adds up the shard's finished worlds and stores
+ * (step tag, count) into word `rank` of every rank's mailbox -- num_ranks stores over xGMI --; phase 2, whose
+ * workgroups poll the num_ranks words of their own mailbox for this step's tag and number the episodes as
+ * mrl_step_phase2_gathered does.  No host call and no collective between the launches, so a captured or free-running
+ * loop needs no rendezvous; every rank must call it the same number of times (a rank that never publishes leaves the others'
+ * phase 2 polling until the bounded wait expires: SCAN_TIMEOUT, as for the persistent rollouts).  One process per rank (a
+ * rank's own handle is not opened).  Reference: one process-wide atomic, src/hanabi_env/sim.cpp:449-451. */
+#define MRL_MAX_RANKS 16
+#define MRL_IPC_HANDLE_BYTES 64
+int mrl_exchange_create(mrl_sim *sim, uint32_t num_ranks, uint32_t rank, uint8_t *ipc_handle_out);
+int mrl_exchange_connect(mrl_sim *sim, const uint8_t *ipc_handles_of_all_ranks);
+int mrl_step_exchanged(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream);
 
 /* Rollout-buffer side of a trainer.  The reference's MAPPO loop clones the observation
  * and state tensors after every step and copies them into the buffer slot of that step

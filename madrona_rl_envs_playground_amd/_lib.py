@@ -22,6 +22,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "mrl_envs.h")
 MRL_OK, MRL_ERR_INVALID, MRL_ERR_DEVICE, MRL_ERR_SLOT = 0, 1, 2, 3
 MRL_INT8, MRL_UINT8, MRL_INT32, MRL_FLOAT32, MRL_UINT32 = 0, 1, 2, 3, 4
 MAX_DIMS = 6
+MAX_RANKS, IPC_HANDLE_BYTES = 16, 64  # MRL_MAX_RANKS, MRL_IPC_HANDLE_BYTES
 
 # every symbol include/mrl_envs.h declares
 SYMBOLS = [
@@ -31,9 +32,9 @@ SYMBOLS = [
     "mrl_abi_version", "mrl_rollout_random", "mrl_step_sequence", "mrl_debug_set", "mrl_probe_stream",
     "mrl_scan_timed_out", "mrl_simplecooked_create", "mrl_launch_shape", "mrl_balance_create", "mrl_step_with_actions_i64",
     "mrl_step_phase2_gathered", "mrl_set_observation_output", "mrl_set_observation_ring", "mrl_prepare_graph_capture", "mrl_step_many",
-    "mrl_build_hash",
+    "mrl_build_hash", "mrl_exchange_create", "mrl_exchange_connect", "mrl_step_exchanged",
 ]
-ABI_VERSION = 3  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
+ABI_VERSION = 4  # MRL_ABI_VERSION of include/mrl_envs.h this binding was written against
 
 
 class TensorDesc(ctypes.Structure):
@@ -148,6 +149,9 @@ def lib():
     L.mrl_step_phase1.argtypes = [vp, vp, vp]
     L.mrl_step_phase2.argtypes = [vp, vp, vp]
     L.mrl_step_phase2_gathered.argtypes = [vp, vp, u32, u32, vp]
+    L.mrl_exchange_create.argtypes = [vp, u32, u32, ctypes.c_char_p]
+    L.mrl_exchange_connect.argtypes = [vp, ctypes.c_char_p]
+    L.mrl_step_exchanged.argtypes = [vp, vp, vp]
     L.mrl_set_observation_output.argtypes = [vp, vp, ctypes.c_uint64]
     L.mrl_set_observation_ring.argtypes = [vp, vp, ctypes.c_uint64, u32]
     L.mrl_prepare_graph_capture.argtypes = [vp, vp]

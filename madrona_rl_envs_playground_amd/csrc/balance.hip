@@ -284,10 +284,11 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, con
                                                                  unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
                                                                  uint32_t *next_counter, uint32_t *__restrict__ reset_count, int32_t *action_out,
                                                                  uint64_t sample_seed, uint32_t sample_step, const mrl::HealTest heal,
-                                                                 const mrl::DeviceCounter device_counter)
+                                                                 const mrl::DeviceCounter device_counter,
+                                                                 const mrl::FusedExchange fx)  // sharded batch: the other ranks' counts (episode_scan.hpp)
 {
     __shared__ uint32_t s_wave[kFusedWorlds][kBlock / 64];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix, s_lower, s_all;
     const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t first = b * (kFusedWorlds * kBlock), last = min(n, first + kFusedWorlds * kBlock);
     const bool last_block = b == gridDim.x - 1, sampled = action_out != nullptr;
@@ -331,10 +332,20 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, con
         const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
             return recount_chunk(n, action, obs, j, sampled, sample_seed, sample_step);
         });
-        if (threadIdx.x == 0) s_prefix = before;
+        uint32_t lower_ranks = 0, all_counts = before + block_total;
+        if (fx.mail.num_ranks) {  // the last workgroup tells every rank the shard's total; the ranks below come first in the numbering
+            lower_ranks = mrl::fused_exchange(fx, last_block, before + block_total, fx.mail.rank);
+            if (last_block) all_counts = mrl::fused_exchange(fx, false, 0u, fx.mail.num_ranks);
+        }
+        if (threadIdx.x == 0) {
+            s_prefix = before;
+            s_lower = lower_ranks;
+            s_all = all_counts;
+        }
     }
     mrl::lds_barrier();
-    const uint32_t before = block_total != 0 || last_block ? s_prefix : 0u;
+    const uint32_t own_before = block_total != 0 || last_block ? s_prefix : 0u;
+    const uint32_t before = own_before + (block_total != 0 || last_block ? s_lower : 0u);
     // (Storing the rows of the worlds that go on while the look-back is under way, and the fresh rows behind it, was measured:
     // 32.6 against 30.4 us per step at 1 M worlds -- the 28-byte rows of neighbouring worlds share cache lines, and writing a
     // line in two passes costs more than the 2 us of waiting.)
@@ -351,8 +362,8 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, con
         }
     }
     if (last_block && threadIdx.x == 0) {
-        *reset_count = before + block_total;
-        *next_counter = base + before + block_total;
+        *reset_count = own_before + block_total;
+        *next_counter = base + s_all;
     }
 }
 
@@ -375,6 +386,8 @@ struct BalanceSim final : mrl_sim {
     uint32_t *block_counts = nullptr, *counter = nullptr, *reset_count = nullptr;
     uint32_t *shard_count = nullptr;  // SHARD_COUNT: finished worlds of the last mrl_step_phase1
     mrl::LaunchStateOwner launch_state;  // parity in device memory once a caller wants to capture steps (common.hpp)
+    mrl::AlarmOwner alarm;               // raised when the mailbox exchange of a sharded step waited in vain (mrl_step_exchanged)
+    bool scan_timed_out() const override { return alarm.raised(); }
     bool capturable() const override { return launch_state.device_mode; }
     void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
@@ -384,13 +397,14 @@ struct BalanceSim final : mrl_sim {
     uint32_t fused_grid = 0, epoch = 0;
     bool fused_step = false;
 
-    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
+    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream,
+                      const mrl::FusedExchange &fx = mrl::FusedExchange{})
     {
         epoch += 1;
         if (launch_state.device_mode) launch_state.advance(stream);
         hipLaunchKernelGGL(mrl_balance_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions ? actions : action, obs, reward,
                            done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed, sample_step, heal,
-                           launch_state.counter_args(counter));
+                           launch_state.counter_args(counter), fx);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -400,6 +414,14 @@ struct BalanceSim final : mrl_sim {
             launch_fused(actions, nullptr, 0, 0, stream);
         else
             mrl_sim::step(actions, stream);
+    }
+    // a shard's step with the other ranks' counts taken from the mailboxes inside the single launch (episode_scan.hpp)
+    void step_exchanged(const int32_t *actions, hipStream_t stream) override
+    {
+        if (fused_step)
+            launch_fused(actions, nullptr, 0, 0, stream, mrl::fused_exchange_of(exchange, alarm.alarm()));
+        else
+            mrl_sim::step_exchanged(actions, stream);
     }
 
     void launch_step(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
@@ -419,7 +441,7 @@ struct BalanceSim final : mrl_sim {
     }
     void publish_shard_count(hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count);
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count, mrl::mail_of(exchange));
         MRL_HIP(hipGetLastError());
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
@@ -428,8 +450,13 @@ struct BalanceSim final : mrl_sim {
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
-        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
+        mrl::GatheredCounts g;
+        g.counts = counts;
+        g.num_ranks = num_ranks;
+        g.rank = rank;
+        launch_reset(counter + parity, g, stream);
     }
+    void phase2_exchanged(hipStream_t stream) override { launch_reset(counter + parity, mrl::polled_counts(exchange, alarm.alarm()), stream); }
     void rollout_random(uint32_t num_steps, uint64_t seed, uint32_t first_step, hipStream_t stream) override
     {
         for (uint32_t k = 0; k < num_steps; k++) {
@@ -525,6 +552,7 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
         sim->reset_count = sim->arena.alloc<uint32_t>(1);
         sim->shard_count = sim->arena.alloc<uint32_t>(1);
         sim->launch_state.init(sim->arena);
+        sim->alarm.init(sim->arena);
         {
             const uint32_t blocks = (num_worlds + kFusedWorlds * kBlock - 1) / (kFusedWorlds * kBlock);
             if (blocks <= mrl::kMaxFusedBlocks) {

@@ -1,5 +1,6 @@
 // extern "C" entry points of libmrl_envs.so (include/mrl_envs.h).
 #include "common.hpp"
+#include "episode_scan.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -308,6 +309,86 @@ int mrl_step_phase2_gathered(mrl_sim *sim, const uint32_t *counts_dev, uint32_t 
     }
     mrl::DeviceGuard on(sim->device);
     return guarded([&] { sim->phase2_gathered(counts_dev, num_ranks, rank, (hipStream_t)hip_stream); });
+}
+
+int mrl_exchange_create(mrl_sim *sim, uint32_t num_ranks, uint32_t rank, uint8_t *ipc_handle_out)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) == MRL_IPC_HANDLE_BYTES, "MRL_IPC_HANDLE_BYTES is hipIpcMemHandle_t's size");
+    if (!ipc_handle_out || num_ranks == 0 || num_ranks > MRL_MAX_RANKS || rank >= num_ranks) {
+        mrl::set_error("mrl_exchange_create: need a handle buffer, 1..%d ranks and rank < num_ranks (got %u of %u)", MRL_MAX_RANKS, rank, num_ranks);
+        return MRL_ERR_INVALID;
+    }
+    if (sim->exchange.mine) {
+        mrl::set_error("mrl_exchange_create: this simulator already has a mailbox");
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(sim->device);
+    return guarded([&] {
+        mrl::ShardExchange &x = sim->exchange;
+        const size_t bytes = sizeof(unsigned long long) * mrl::kMailSlots * MRL_MAX_RANKS;
+        void *block = nullptr;
+        // fine-grained: the peers' stores must become visible to a kernel of this device that is already running
+        if (hipExtMallocWithFlags(&block, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            MRL_HIP(hipMalloc(&block, bytes));
+        }
+        x.mine = static_cast<unsigned long long *>(block);
+        MRL_HIP(hipMemset(x.mine, 0, bytes));
+        MRL_HIP(hipDeviceSynchronize());
+        hipIpcMemHandle_t handle;
+        MRL_HIP(hipIpcGetMemHandle(&handle, x.mine));
+        memcpy(ipc_handle_out, &handle, sizeof(handle));
+        x.num_ranks = num_ranks;
+        x.rank = rank;
+        x.step = 0;
+    });
+}
+
+int mrl_exchange_connect(mrl_sim *sim, const uint8_t *ipc_handles_of_all_ranks)
+{
+    if (int rc = mrl::need(sim)) return rc;
+    mrl::ShardExchange &x = sim->exchange;
+    if (!ipc_handles_of_all_ranks || !x.mine || x.connected) {
+        mrl::set_error("mrl_exchange_connect: call mrl_exchange_create first, once, and pass the handles of all ranks");
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(sim->device);
+    return guarded([&] {
+        for (uint32_t p = 0; p < x.num_ranks; p++) {
+            if (p == x.rank) {
+                x.peer[p] = x.mine;  // (a process cannot open its own handle)
+                continue;
+            }
+            hipIpcMemHandle_t handle;
+            memcpy(&handle, ipc_handles_of_all_ranks + (size_t)p * sizeof(handle), sizeof(handle));
+            void *mapped = nullptr;
+            MRL_HIP(hipIpcOpenMemHandle(&mapped, handle, hipIpcMemLazyEnablePeerAccess));
+            x.peer[p] = static_cast<unsigned long long *>(mapped);
+        }
+        x.connected = true;
+    });
+}
+
+int mrl_step_exchanged(mrl_sim *sim, const int32_t *actions_dev_or_null, void *hip_stream)
+{
+    if (int rc = mrl::need_healthy(sim)) return rc;
+    if (int rc = mrl::need_not_capturing(sim, hip_stream, "mrl_step_exchanged")) return rc;
+    if (!sim->exchange.connected) {
+        mrl::set_error("mrl_step_exchanged: no connected mailbox (mrl_exchange_create, mrl_exchange_connect)");
+        return MRL_ERR_INVALID;
+    }
+    mrl::DeviceGuard on(sim->device);
+    return guarded([&] {
+        mrl::ShardExchange &x = sim->exchange;
+        x.step += 1;  // this step's tag: the words of step k live in slot k % kMailSlots
+        x.publishing = true;
+        struct Done {
+            mrl::ShardExchange &x;
+            ~Done() { x.publishing = false; }
+        } done{x};
+        sim->step_exchanged(actions_dev_or_null, (hipStream_t)hip_stream);
+    });
 }
 
 int mrl_set_observation_output(mrl_sim *sim, void *obs_dev_or_null, uint64_t bytes)

@@ -421,7 +421,8 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
                                                                   uint32_t *next_counter,
                                                                   uint32_t *__restrict__ reset_count,
                                                                   int32_t *action_out, uint64_t sample_seed, uint32_t sample_step,
-                                                                  const mrl::HealTest heal, const mrl::DeviceCounter device_counter
+                                                                  const mrl::HealTest heal, const mrl::DeviceCounter device_counter,
+                                                                  const mrl::FusedExchange fx  // sharded batch: the other ranks' counts (episode_scan.hpp)
 #ifdef MRL_DIAG
                                                                   , unsigned long long *stamps  // diagnostic build: s_memrealtime stamps per wave
 #endif
@@ -442,7 +443,7 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     __builtin_amdgcn_s_setprio(3);
     // action_out != nullptr: the reference harness's randint(high=2) drawn here (random_policy.hpp)
     __shared__ uint32_t s_votes[kUnroll][kBlock / 64];
-    __shared__ uint32_t s_prefix;
+    __shared__ uint32_t s_prefix, s_all_ranks;
     __shared__ uint32_t s_list[kBlock / 64][kUnroll * 64];  // per wave: its finished worlds, (rank in the workgroup << 16) | local index
     const uint32_t b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
@@ -537,8 +538,18 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
                 mrl::lookback_issue<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, words);
                 return mrl::wave_sum(mrl::lookback_finish<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, epoch, heal, words, recount));
             };
-            const uint32_t below = mrl::wave_sum(mrl::lookback_finish<1>(group_total, 0, group, epoch, mrl::HealTest{}, lower_groups, regroup));
-            if (lane == 0) s_prefix = below + in_group;
+            uint32_t before = in_group + mrl::wave_sum(mrl::lookback_finish<1>(group_total, 0, group, epoch, mrl::HealTest{}, lower_groups, regroup));
+            if (fx.mail.num_ranks) {
+                // a shard of a larger batch: the last workgroup knows the shard's total and tells every rank; the ranks
+                // below this one come first in the numbering, and the counter moves on by the sum over all ranks
+                const uint32_t shard_total = before + block_total;  // (meaningful in the last workgroup)
+                before += mrl::fused_exchange(fx, last_block, shard_total, fx.mail.rank);
+                if (last_block) {
+                    const uint32_t all_ranks = mrl::fused_exchange(fx, false, 0u, fx.mail.num_ranks);
+                    if (lane == 0) s_all_ranks = all_ranks;
+                }
+            }
+            if (lane == 0) s_prefix = before;
         }
     }
     CP_STAMP(5);
@@ -562,9 +573,17 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     }
     CP_STAMP(7);
     if (last_block && threadIdx.x == 0) {
-        const uint32_t grand_total = prefix + block_total;  // the whole GPU's
-        *reset_count = grand_total;
-        *next_counter = base + grand_total;
+        if (fx.mail.num_ranks) {
+            // prefix includes the ranks below: this shard's own total is what its look-back and its own count add up to
+            uint32_t lower = 0;
+            for (uint32_t r = 0; r < fx.mail.rank; r++) lower += (uint32_t)fx.mine[(fx.mail.tag % mrl::kMailSlots) * MRL_MAX_RANKS + r];
+            *reset_count = prefix - lower + block_total;
+            *next_counter = base + s_all_ranks;
+        } else {
+            const uint32_t grand_total = prefix + block_total;  // the whole GPU's
+            *reset_count = grand_total;
+            *next_counter = base + grand_total;
+        }
     }
 }
 
@@ -751,14 +770,15 @@ struct CartpoleSim final : mrl_sim {
         launch_fused(actions ? actions : action, nullptr, 0, 0, stream);
     }
 
-    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream)
+    void launch_fused(const int32_t *actions, int32_t *action_out, uint64_t seed, uint32_t sample_step, hipStream_t stream,
+                      const mrl::FusedExchange &fx = mrl::FusedExchange{})
     {
         epoch += 1;
         if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
         with_variant(variant, [&](auto v) {
             hipLaunchKernelGGL(mrl_cartpole_step_fused<decltype(v)::value>, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds,
                                actions, state, reward, done, status, group_total, epoch, counter + parity, counter + (parity ^ 1u), reset_count,
-                               action_out, seed, sample_step, heal, launch_state.counter_args(counter)
+                               action_out, seed, sample_step, heal, launch_state.counter_args(counter), fx
 #ifdef MRL_DIAG
                                , stamps
 #endif
@@ -766,6 +786,16 @@ struct CartpoleSim final : mrl_sim {
         });
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
+    }
+
+    // a shard's step with the other ranks' counts taken from the mailboxes inside the single launch (episode_scan.hpp)
+    void step_exchanged(const int32_t *actions, hipStream_t stream) override
+    {
+        if (fused_grid == 0 || !fused_step) {
+            mrl_sim::step_exchanged(actions, stream);
+            return;
+        }
+        launch_fused(actions ? actions : action, nullptr, 0, 0, stream, mrl::fused_exchange_of(exchange, alarm.alarm()));
     }
 
     unsigned long long *ring = nullptr;
@@ -827,7 +857,7 @@ struct CartpoleSim final : mrl_sim {
     }
     void publish_shard_count(hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count);
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, block_counts, grid, shard_count, mrl::mail_of(exchange));
         MRL_HIP(hipGetLastError());
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
@@ -836,8 +866,13 @@ struct CartpoleSim final : mrl_sim {
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
-        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
+        mrl::GatheredCounts g;
+        g.counts = counts;
+        g.num_ranks = num_ranks;
+        g.rank = rank;
+        launch_reset(counter + parity, g, stream);
     }
+    void phase2_exchanged(hipStream_t stream) override { launch_reset(counter + parity, mrl::polled_counts(exchange, alarm.alarm()), stream); }
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
     {

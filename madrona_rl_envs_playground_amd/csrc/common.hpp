@@ -164,12 +164,31 @@ inline mrl_tensor_desc make_desc(void *data, int dtype, int device, std::initial
 
 }  // namespace mrl
 
+namespace mrl {
+// The mailbox of the collective-free shard exchange (mrl_exchange_*; the protocol is in episode_scan.hpp).
+struct ShardExchange {
+    uint32_t num_ranks = 0, rank = 0;
+    uint32_t step = 0;                            // tag of the current step's words
+    unsigned long long *mine = nullptr;           // kMailSlots x MRL_MAX_RANKS words, word r of a slot written by rank r
+    unsigned long long *peer[MRL_MAX_RANKS] = {}; // rank p's block as mapped here (peer[rank] == mine)
+    bool connected = false;
+    bool publishing = false;                      // inside mrl_step_exchanged: the count launch also writes the mailboxes
+    ~ShardExchange()
+    {
+        for (uint32_t p = 0; p < num_ranks; p++)
+            if (connected && p != rank && peer[p]) (void)hipIpcCloseMemHandle(peer[p]);
+        if (mine) (void)hipFree(mine);
+    }
+};
+}  // namespace mrl
+
 // The opaque handle of the C ABI.
 struct mrl_sim {
     int game = 0;
     int device = 0;
     uint32_t num_worlds = 0;
     mrl::DeviceArena arena;
+    mrl::ShardExchange exchange;
 
     virtual ~mrl_sim() {}
     // actions == nullptr -> read the simulator's own ACTION tensor
@@ -180,7 +199,17 @@ struct mrl_sim {
     // Games without an episode counter have nothing to do.
     virtual void phase2_gathered(const uint32_t *, uint32_t, uint32_t, hipStream_t) {}
     // mrl_step_phase1 only (mrl_step does not pay for it): the shard's finished worlds of the phase 1 just enqueued -> SHARD_COUNT
+    // (and, for mrl_step_exchanged, into the peers' mailboxes: `exchange`)
     virtual void publish_shard_count(hipStream_t) {}
+    // phase 2 of mrl_step_exchanged: like phase2_gathered, the counts polled from this rank's mailbox
+    virtual void phase2_exchanged(hipStream_t) {}
+    // mrl_step_exchanged: three launches by default; a game whose single-launch step does the exchange itself overrides it
+    virtual void step_exchanged(const int32_t *actions, hipStream_t stream)
+    {
+        phase1(actions, stream);
+        publish_shard_count(stream);
+        phase2_exchanged(stream);
+    }
     // whole step; games whose step is two launches may override it with a single fused launch
     virtual void step(const int32_t *actions, hipStream_t stream)
     {

@@ -37,8 +37,24 @@ __device__ __forceinline__ void lds_barrier()
 // kernel itself was measured first: 1024 same-address atomics drain at ~8 ns each and the launch cannot end before
 // they have -- Cartpole at 1 M worlds 14.9 -> 22.8 us per step, paid by unsharded runs too.)  Between the phases the
 // ranks all-gather the word, and phase 2 of rank r takes base = own counter + counts of the ranks below r.
+//
+// The exchange itself has two forms.  (1) A collective: the caller all-gathers the ranks' SHARD_COUNT words (RCCL) and hands
+// them to mrl_step_phase2_gathered.  (2) A MAILBOX (mrl_exchange_*, round 4): every rank owns a small block of
+// fine-grained device memory that its peers have mapped through IPC handles; the count launch of rank r stores
+// (step tag, count) into word r of EVERY rank's mailbox -- G plain stores over xGMI -- and phase 2 polls the G words of
+// its own mailbox for this step's tag: no host call, no collective, nothing between the launches of a step.  A rank can
+// be at most one step ahead of a peer that has not read yet (its next count needs that peer's next word), so the words
+// live in a ring of kMailSlots step slots.  The wait is bounded like the persistent rollouts' (SCAN_TIMEOUT).
+constexpr uint32_t kMailSlots = 4;
+
+struct ShardMail {  // where the count launch publishes to (all zero: nowhere)
+    unsigned long long *peer[MRL_MAX_RANKS];  // rank p's mailbox as mapped into this process (peer[rank] is this rank's own)
+    uint32_t num_ranks, rank, tag;
+};
+
 __attribute__((unused)) static __global__ void __launch_bounds__(256) sum_block_counts(const uint32_t *__restrict__ block_counts,
-                                                                                       uint32_t num_blocks, uint32_t *__restrict__ shard_count)
+                                                                                       uint32_t num_blocks, uint32_t *__restrict__ shard_count,
+                                                                                       const ShardMail mail)
 {
     __shared__ uint32_t s_wave[4];
     uint32_t mine = 0;
@@ -46,25 +62,123 @@ __attribute__((unused)) static __global__ void __launch_bounds__(256) sum_block_
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
     if ((threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) *shard_count = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (threadIdx.x == 0) *shard_count = total;
+    if (threadIdx.x < mail.num_ranks)  // one store per peer, into that peer's memory
+        __hip_atomic_store(&mail.peer[threadIdx.x][(mail.tag % kMailSlots) * MRL_MAX_RANKS + mail.rank],
+                           ((unsigned long long)mail.tag << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct GatheredCounts {
     const uint32_t *counts = nullptr;  // nullptr: not a gathered phase 2
     uint32_t num_ranks = 0, rank = 0;
+    // mailbox form: the words are polled for `tag` (then `counts` only says "sharded": it points at the mailbox too)
+    const unsigned long long *mail = nullptr;
+    uint32_t tag = 0;
+    Alarm timed_out{};
 };
 
-// finished worlds of the ranks below this one (uniform scalar loads); *all = of every rank
+// finished worlds of the ranks below this one (uniform loads); *all = of every rank
 __device__ __forceinline__ uint32_t lower_ranks(const GatheredCounts &g, uint32_t *all)
 {
     uint32_t below = 0, total = 0;
     for (uint32_t r = 0; r < g.num_ranks; r++) {
-        const uint32_t v = g.counts[r];
+        uint32_t v;
+        if (g.mail) {
+            const unsigned long long *word = &g.mail[(g.tag % kMailSlots) * MRL_MAX_RANKS + r];
+            unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (uint32_t polls = 0; (uint32_t)(w >> 32) != g.tag; polls++) {
+                if (polls == (1u << 22)) {  // ~1 s: a peer never published this step
+                    g.timed_out.raise();
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            v = (uint32_t)w;
+        } else {
+            v = g.counts[r];
+        }
         below += r < g.rank ? v : 0u;
         total += v;
     }
     *all = total;
     return below;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+{
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// The single-launch steps take part in the same exchange from INSIDE the kernel (mrl_step_exchanged where the game's
+// single launch exists): the last workgroup, whose look-back yields the shard's total, stores the word into every peer's
+// mailbox; the wave of every workgroup that needs a prefix then adds the words of the ranks below (lane r polls word r),
+// and the last workgroup the words of all ranks for the counter.  One launch per step, one hop over xGMI behind the
+// shard's own look-back.  Unlike the look-back among the workgroups of one GPU this wait cannot heal itself -- another
+// rank's inputs are out of reach -- so it is bounded and raises the alarm, like a collective whose peer never arrives.
+struct FusedExchange {
+    ShardMail mail;                   // num_ranks == 0: not a sharded step
+    const unsigned long long *mine;   // this rank's mailbox
+    Alarm timed_out;
+};
+
+// (wave-uniform call) publishes `shard_total` if `publish`, then returns to every lane the sum of the words of ranks
+// [0, upto) of this step
+__device__ __forceinline__ uint32_t fused_exchange(const FusedExchange &fx, bool publish, uint32_t shard_total, uint32_t upto)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t slot = (fx.mail.tag % kMailSlots) * MRL_MAX_RANKS;
+    if (publish && lane < fx.mail.num_ranks)
+        __hip_atomic_store(&fx.mail.peer[lane][slot + fx.mail.rank], ((unsigned long long)fx.mail.tag << 32) | shard_total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t v = 0;
+    if (lane < upto) {
+        unsigned long long w = __hip_atomic_load(&fx.mine[slot + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (uint32_t polls = 0; (uint32_t)(w >> 32) != fx.mail.tag; polls++) {
+            if (polls == (1u << 22)) {
+                fx.timed_out.raise();
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            w = __hip_atomic_load(&fx.mine[slot + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        v = (uint32_t)w;
+    }
+    return wave_sum(v);
+}
+
+// host side: the kernel arguments of the two launches from the simulator's ShardExchange (common.hpp)
+inline ShardMail mail_of(const ShardExchange &x)
+{
+    ShardMail m{};
+    if (x.connected && x.publishing) {
+        for (uint32_t p = 0; p < x.num_ranks; p++) m.peer[p] = x.peer[p];
+        m.num_ranks = x.num_ranks;
+        m.rank = x.rank;
+        m.tag = x.step;
+    }
+    return m;
+}
+inline FusedExchange fused_exchange_of(const ShardExchange &x, const Alarm &alarm)
+{
+    FusedExchange f{};
+    f.mail = mail_of(x);
+    f.mine = x.mine;
+    f.timed_out = alarm;
+    return f;
+}
+inline GatheredCounts polled_counts(const ShardExchange &x, const Alarm &alarm)
+{
+    GatheredCounts g;
+    g.counts = reinterpret_cast<const uint32_t *>(x.mine);  // "a sharded phase 2"; the words themselves are read through `mail`
+    g.num_ranks = x.num_ranks;
+    g.rank = x.rank;
+    g.mail = x.mine;
+    g.tag = x.step;
+    g.timed_out = alarm;
+    return g;
 }
 
 // ---- device-resident launch state (mrl_prepare_graph_capture; common.hpp LaunchState) ----
@@ -308,11 +422,6 @@ __device__ __forceinline__ uint32_t lookback_finish(const Word *status, uint32_t
     return before;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
-{
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
 
 // Sum of the counts of workgroups [from, block) for `epoch`, to every lane of the calling wave.
 template <typename Word, typename Recount>

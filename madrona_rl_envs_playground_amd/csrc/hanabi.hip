@@ -1368,7 +1368,8 @@ __global__ void __launch_bounds__(kFusedBlock) __attribute__((amdgpu_waves_per_e
 mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_t hot_num_worlds, uint32_t heal_mod, uint32_t pair_stride,
                       const HanabiParams p0,
                       unsigned long long *status, uint32_t epoch, const uint32_t *episode_base, uint32_t *next_counter,
-                      uint32_t *reset_count, uint32_t *heal_seen, const mrl::DeviceCounter device_counter)
+                      uint32_t *reset_count, uint32_t *heal_seen, const mrl::DeviceCounter device_counter,
+                      const mrl::FusedExchange fx)  // sharded batch: the other ranks' counts through the mailboxes (episode_scan.hpp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t smem[kWavesPerBlock * kWaveLdsBytes];
     __shared__ __attribute__((aligned(16))) uint8_t s_scratch[kWorldsPerWave * kRecStride];  // the scan wave's copy of another workgroup's records (healing)
@@ -1419,11 +1420,18 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&s_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FSTAMP_SCAN(1);
+        uint32_t lower_ranks = 0, all_counts = before + block_total;
+        if (fx.mail.num_ranks) {
+            // a shard of a larger batch: the last workgroup tells every rank the shard's total; the ranks below come first in the
+            // numbering, and the counter moves on by the sum over all ranks
+            if (block_total != 0 || last_block) lower_ranks = mrl::fused_exchange(fx, last_block, before + block_total, fx.mail.rank);
+            if (last_block) all_counts = mrl::fused_exchange(fx, false, 0u, fx.mail.num_ranks);
+        }
         if (last_block && lane == 0) {
             *reset_count = before + block_total;
-            *next_counter = base + before + block_total;
+            *next_counter = base + all_counts;
         }
-        deal_finished_worlds<kV>(p, [&](uint32_t wv) { return wave_lds(smem, wv); }, s_fin, start_of, base + before, lane);
+        deal_finished_worlds<kV>(p, [&](uint32_t wv) { return wave_lds(smem, wv); }, s_fin, start_of, base + lower_ranks + before, lane);
         if (lane == 0) __hip_atomic_store(&s_ready, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FSTAMP_SCAN(2);
         return;
@@ -1735,6 +1743,19 @@ struct HanabiSim final : mrl_sim {
             mrl_sim::step(actions, stream);
             return;
         }
+        launch_fused(actions, stream, mrl::FusedExchange{});
+    }
+    // a shard's step with the other ranks' counts taken from the mailboxes inside the single launch (episode_scan.hpp)
+    void step_exchanged(const int32_t *actions, hipStream_t stream) override
+    {
+        if (!fused) {
+            mrl_sim::step_exchanged(actions, stream);
+            return;
+        }
+        launch_fused(actions, stream, mrl::fused_exchange_of(exchange, alarm.alarm()));
+    }
+    void launch_fused(const int32_t *actions, hipStream_t stream, const mrl::FusedExchange &fx)
+    {
         HanabiParams a = params;
         a.actions = actions ? actions : action;
         epoch += 1;
@@ -1743,9 +1764,9 @@ struct HanabiSim final : mrl_sim {
         if (launch_state.device_mode) launch_state.advance(stream);  // then parity / epoch come from device memory
         const mrl::DeviceCounter dc = launch_state.counter_args(counter);
         switch (variant) {
-        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
-        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
-        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc); break;
+        case 2: hipLaunchKernelGGL((mrl_hanabi_step_fused<2>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc, fx); break;
+        case 1: hipLaunchKernelGGL((mrl_hanabi_step_fused<1>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc, fx); break;
+        default: hipLaunchKernelGGL((mrl_hanabi_step_fused<0>), dim3(grid), dim3(kFusedBlock), 0, stream, a.records, a.actions, a.num_worlds, heal.mod, pair_stride, a, status, epoch, base, next, reset_count, heal.seen, dc, fx); break;
         }
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
@@ -1837,7 +1858,7 @@ struct HanabiSim final : mrl_sim {
     }
     void publish_shard_count(hipStream_t stream) override
     {
-        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, params.block_counts, grid, params.shard_count);
+        hipLaunchKernelGGL(mrl::sum_block_counts, dim3(1), dim3(256), 0, stream, params.block_counts, grid, params.shard_count, mrl::mail_of(exchange));
         MRL_HIP(hipGetLastError());
     }
     void phase2(const uint32_t *episode_base_dev, hipStream_t stream) override
@@ -1846,8 +1867,13 @@ struct HanabiSim final : mrl_sim {
     }
     void phase2_gathered(const uint32_t *counts, uint32_t num_ranks, uint32_t rank, hipStream_t stream) override
     {
-        launch_reset(counter + parity, mrl::GatheredCounts{counts, num_ranks, rank}, stream);
+        mrl::GatheredCounts g;
+        g.counts = counts;
+        g.num_ranks = num_ranks;
+        g.rank = rank;
+        launch_reset(counter + parity, g, stream);
     }
+    void phase2_exchanged(hipStream_t stream) override { launch_reset(counter + parity, mrl::polled_counts(exchange, alarm.alarm()), stream); }
 
     void set_episode_counter(uint32_t next_episode, hipStream_t stream) override
     {

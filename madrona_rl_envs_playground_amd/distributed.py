@@ -21,6 +21,13 @@ collective is needed to *step*.  Two optional exchanges exist:
   (``mrl_step_phase2_gathered``) adds up the lower ranks' itself -- a sharded step is two launches
   and one collective, no torch arithmetic in between.
 
+Since round 4 the episode-number exchange can also run WITHOUT a collective (``ShardedSimulator(..., exchange="mailbox")``):
+every rank owns a small device mailbox that its peers map through IPC handles (exchanged once, at construction); the count
+launch of a step stores the rank's word into every peer's mailbox over xGMI and phase 2 polls its own -- a sharded step is then
+``mrl_step_exchanged``: three launches, no host call and no RCCL call in between (the 4-byte all-gather costs 10-15 us per
+step, more than the step itself).  The collective stays the default: the mailbox has run on one GPU only (one rank, and two
+processes sharing the card), never across xGMI.
+
 A process group of ONE rank still runs every collective (RCCL at world_size 1 is how the ``nccl``
 code path is exercised on a one-GPU box, tests/test_gpu_nccl.py); without a process group the
 gathers are identities and no collective is issued.
@@ -93,7 +100,10 @@ class ShardedSimulator:
     ``total_worlds`` exactly as in a single simulator of the whole batch.
     """
 
-    def __init__(self, factory, total_worlds, group=None, needs_episode_exchange=True):
+    def __init__(self, factory, total_worlds, group=None, needs_episode_exchange=True, exchange="collective"):
+        if exchange not in ("collective", "mailbox"):
+            raise ValueError("exchange must be 'collective' or 'mailbox'")
+        self.exchange = exchange
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -105,10 +115,21 @@ class ShardedSimulator:
             self.sim.reseed_shard(self.lo, self.total_worlds)  # world i = global world lo + i; the counter starts at total_worlds
             self._mine = self.sim.shard_count_tensor().to_torch()  # one word, written by phase 1
             self._counts = torch.zeros((self.world_size,), dtype=self._mine.dtype, device=self._mine.device)
+            if exchange == "mailbox":
+                # one mailbox per rank, mapped by every peer: the only collective of this mode, once
+                mine = self.sim.exchange_create(self.world_size, self.rank)
+                handles = [mine]
+                if dist.is_initialized() and self.world_size > 1:
+                    handles = [None] * self.world_size
+                    dist.all_gather_object(handles, mine, group=group)
+                self.sim.exchange_connect(handles)
 
     def step(self, actions=None):
         """One step of this rank's worlds.  ``actions``: rank-local action tensor
         (or None to use the simulator's ACTION tensor)."""
+        if self.needs_episode_exchange and self.exchange == "mailbox":
+            self.sim.step_exchanged(actions)  # phase 1, count + publish into the peers' mailboxes, phase 2 polling its own
+            return
         if not self.needs_episode_exchange or not dist.is_initialized():
             # no exchange to make: Overcooked has no episode counter, and without a process group this one shard IS the whole
             # batch, so the simulator's own counter is the global one and the library's best single-GPU step applies

@@ -245,6 +245,26 @@ class _Simulator:
         ptr = self._word_pointer(counts, counts.numel(), "counts")
         _lib.check(self._L.mrl_step_phase2_gathered(self._handle, ptr, int(counts.numel()), int(rank), _stream_ptr(self.gpu_id)))
 
+    def exchange_create(self, num_ranks, rank):
+        """This rank's mailbox of the collective-free shard exchange (``mrl_exchange_create``) -> its IPC handle (64 bytes),
+        to be handed to every rank."""
+        buf = ctypes.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+        _lib.check(self._L.mrl_exchange_create(self._handle, int(num_ranks), int(rank), buf))
+        return buf.raw
+
+    def exchange_connect(self, handles):
+        """``handles``: the IPC handles of all ranks, in rank order (``mrl_exchange_connect``)."""
+        blob = b"".join(handles)
+        if len(blob) % _lib.IPC_HANDLE_BYTES:
+            raise ValueError("handles must be 64 bytes each")
+        _lib.check(self._L.mrl_exchange_connect(self._handle, blob))
+
+    def step_exchanged(self, actions=None):
+        """One step of a shard whose ranks exchange their finished counts through the mailboxes (``mrl_step_exchanged``):
+        phase 1, count + publish, phase 2 polling -- no collective, no host call in between."""
+        ptr = None if actions is None else self._action_pointer(actions)
+        _lib.check(self._L.mrl_step_exchanged(self._handle, ptr, _stream_ptr(self.gpu_id)))
+
     def set_observation_output(self, out):
         """Later steps write their observations into ``out`` -- an int8 CUDA tensor of the world-major shape
         (N, P, H, W, F), contiguous, e.g. one slot of a rollout buffer -- instead of the simulator's own tensor; ``None``

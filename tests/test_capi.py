@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for sym in declared_symbols():
         assert hasattr(hip_lib, sym), f"libmrl_envs.so does not export {sym}"
     from madrona_rl_envs_playground_amd import _lib
-    assert hip_lib.mrl_abi_version() == _lib.ABI_VERSION == 3
+    assert hip_lib.mrl_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_library_is_gfx950_only():

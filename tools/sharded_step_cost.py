@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What the sharded step's own machinery costs on ONE rank, without a collective: mrl_step (the library's choice), the
 two-launch pair, and ShardedSimulator.step at world_size 1 -- phase 1 + the one-workgroup count launch + phase 2 (no process
-group), and with a one-rank nccl group (all-gather of one int32 over RCCL + mrl_step_phase2_gathered).  us per step."""
+group), with a one-rank nccl group (all-gather of one int32 over RCCL + mrl_step_phase2_gathered), and with the
+collective-free mailbox exchange (mrl_step_exchanged).  us per step."""
 import json
 import os
 import sys
@@ -71,6 +72,10 @@ def main():
             sim.step_phase2_gathered(counts, 0)
         row["phase1_count_phase2_gathered_us"] = us(two_phase)
         sim.close()
+        # the collective-free exchange (mrl_step_exchanged): phase 1 + count-and-publish launch + phase 2 polling its mailbox
+        sh = ShardedSimulator(make, n, exchange="mailbox")
+        row["sharded_step_mailbox_us"] = us(lambda i: sh.step())
+        sh.close()
         out[name] = row
     print(json.dumps(out))
     if with_group:
