@@ -224,6 +224,8 @@ def expected_gather(shard_bytes, world_size, step_seconds):
     figure, point to point).  Upper bound on the bus bandwidth: all G - 1 peers' links streaming at the link rate; lower: RCCL's
     ring (one link's worth, ~60 % efficient).  `gather_ms_per_step` follows from bytes / busbw."""
     peers = world_size - 1
+    if peers == 0:
+        return {"basis": "world_size 1: the collective is a device-to-device copy of the shard, no link is crossed"}
     recv = shard_bytes * peers
     hi = peers * 153.0          # direct all-gather, every peer on its own link at the link rate
     lo = 0.6 * 153.0            # ring: one link's rate at RCCL's usual efficiency
