@@ -448,7 +448,7 @@ void mrl_destroy(mrl_sim *sim);
  * overcooked.wpw, overcooked.whole_max, overcooked.lds_max, overcooked.share_max_players, overcooked.share_private,
  * overcooked.no_share, overcooked.lds_pad, overcooked.no_fixed, overcooked.no_direct, overcooked.whole_store,
  * overcooked.store_policy, overcooked.wide_rollout, overcooked.groups, overcooked.shared_consts, overcooked.variant,
- * hanabi.variant, hanabi.pairing, hanabi.no_persistent, cartpole.no_persistent, cartpole.variant, fused_step (0 the library's choice, 1 one launch,
+ * hanabi.variant, hanabi.pairing, hanabi.no_persistent, cartpole.no_persistent, cartpole.persistent_max, cartpole.variant, fused_step (0 the library's choice, 1 one launch,
  * 2 two launches), fused_heal_test, inject_scan_timeout, and (diagnostic build) ablate, stamps.  key == NULL forgets all of
  * them.  Unknown key: MRL_ERR_INVALID.  No reference counterpart (the reference has MADRONA_* environment variables for its
  * JIT cache only). */

@@ -36,6 +36,7 @@ static const char *const kDebugKeys[] = {
                              // 64 lanes, 1 the pairs are (2k, 2k + 1), 0 every wave steps its own 32 worlds
     "hanabi.no_persistent",  // 1: mrl_rollout_random as one launch per step
     "cartpole.no_persistent",
+    "cartpole.persistent_max",  // largest batch mrl_rollout_random runs as ONE persistent launch (above: one single-launch step per step)
     "cartpole.variant",      // arithmetic of the transition: 0 the library's default, 1 typed and rounded as the reference writes it (four double
                              // divisions), 2 the same float roundings around fused double intermediates and reciprocals, 3 = 2 with sin/cos
                              // evaluated without range reduction while |theta| <= pi/4 (the default), 4 float throughout (csrc/cartpole.hip)

@@ -72,23 +72,6 @@ __device__ __forceinline__ float4 fresh_state(uint32_t episode)
     return s;
 }
 
-// counts the set flags of a workgroup; returns this thread's exclusive rank
-__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t *s_wave, uint32_t &block_total)
-{
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long votes = __ballot(flag);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(votes);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < kBlock / 64; w++) {
-        const uint32_t c = s_wave[w];
-        before += w < wave ? c : 0;
-        total += c;
-    }
-    block_total = total;
-    return before + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull));
-}
-
 // ---- the transition (sim.cpp:68-96), in four arithmetic variants (mrl_debug_set "cartpole.variant") ----
 // The reference mixes float state with double literals, so nearly every intermediate is a double and the three
 // quotients by TOTAL_MASS plus the one by the pole term are four IEEE double divisions (v_div_scale x2 / v_rcp /
@@ -595,9 +578,10 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
 // launches it cooperatively (the runtime refuses a grid the device cannot hold) and otherwise runs
 // one launch per step; waits are bounded (SCAN_TIMEOUT).
 constexpr int kRing = 4;
+constexpr int64_t kPersistentMaxWorlds = 1 << 30;  // (set from the measurement below)
 
 template <int V>
-__global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float4 *__restrict__ state, float *__restrict__ reward,
+__global__ void __launch_bounds__(kBlock, 4) mrl_cartpole_rollout(uint32_t n, float4 *__restrict__ state, float *__restrict__ reward,
                                                                int32_t *__restrict__ done, int32_t *__restrict__ action_out,
                                                                unsigned long long *ring, uint32_t epoch0, uint32_t num_steps,
                                                                uint32_t first_step, uint64_t seed,
@@ -605,10 +589,13 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
                                                                uint32_t *__restrict__ next_counter,
                                                                uint32_t *__restrict__ reset_count, const mrl::Alarm timed_out)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_votes[kUnroll][kBlock / 64];
     __shared__ uint32_t s_red[2 * kBlock / 64];
+    __shared__ uint32_t s_list[kBlock / 64][kUnroll * 64];  // per wave: its finished worlds, (rank in the workgroup << 16) | local index
+    __shared__ float4 s_fresh[kBlock / 64][kUnroll * 64];   // ... and their next episodes' states, on their way back to the owners' registers
     const uint32_t G = gridDim.x, b = blockIdx.x;
     const uint32_t first = b * (kUnroll * kBlock), last = min(n, first + kUnroll * kBlock);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool last_block = b == G - 1;
     float4 s[kUnroll];
 #pragma unroll
@@ -621,35 +608,43 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
         const uint32_t epoch = epoch0 + k;
         unsigned long long *now = ring + (size_t)(epoch % kRing) * G;
         const unsigned long long *before_step = ring + (size_t)((epoch - 1u) % kRing) * G;
+        // the same order of events as in the single-launch step: who finishes (two multiply-adds per world), the count
+        // published, then the expensive half while the count travels; the finished worlds of a wave re-seeded in one pass
         bool over[kUnroll];
         int32_t drawn[kUnroll];
-        uint32_t finished = 0;
+        unsigned long long votes[kUnroll];
+        float ntheta[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             const uint32_t i = first + u * kBlock + threadIdx.x;
             drawn[u] = (int32_t)(mrl::policy_hash(seed, first_step + k, i < last ? i : first, 0) >> 31);
+            float nx;
+            over[u] = next_pose<V>(s[u], nx, ntheta[u]) && i < last;
+            s[u].x = nx;  // (the expensive half does not look at the position: no register of its own)
+            votes[u] = __ballot(over[u]);
+            if (lane == 0) s_votes[u][wave] = (uint32_t)__popcll(votes[u]);
         }
-        advance<V, kUnroll>(s, drawn, over);
+        mrl::lds_barrier();
+        uint32_t block_total = 0, wave_total = 0;
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
-            const uint32_t i = first + u * kBlock + threadIdx.x;
-            const int32_t a = drawn[u];
-            over[u] = over[u] && i < last;
-            finished += over[u] ? 1u : 0u;
-            if (i < last) {
-                action_out[i] = a;
-                if (!over[u]) state[i] = s[u];
-                reward[i] = 1.f;
-                done[i] = over[u] ? 1 : 0;
+            uint32_t before_me = block_total;
+            for (uint32_t w = 0; w < kBlock / 64; w++) {
+                const uint32_t c = s_votes[u][w];
+                before_me += w < wave ? c : 0u;
+                block_total += c;
             }
+            const uint32_t below = (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
+            if (over[u]) s_list[wave][wave_total + below] = ((before_me + below) << 16) | (uint32_t)(u * kBlock + threadIdx.x);
+            wave_total += (uint32_t)__popcll(votes[u]);
         }
-        for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off, 64);
-        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = finished;
-        mrl::lds_barrier();
-        uint32_t block_total = 0;
-        for (uint32_t w = 0; w < kBlock / 64; w++) block_total += s_wave[w];
         if (threadIdx.x == 0) mrl::publish_count(now, b, epoch, block_total);
-        mrl::lds_barrier();  // s_wave is reused below
+        {
+            float nxd[kUnroll], nthd[kUnroll];
+            next_rates<V, kUnroll>(s, drawn, nxd, nthd);
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) s[u] = make_float4(s[u].x, nxd[u], ntheta[u], nthd[u]);
+        }
         // lower workgroups of this step (only if somebody here finished) and everybody's previous step
         uint32_t lower = 0, prev_all = 0, unused = 0;
         if (k > 0)
@@ -660,9 +655,9 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
             lower += __shfl_down(lower, off, 64);
             prev_all += __shfl_down(prev_all, off, 64);
         }
-        if ((threadIdx.x & 63) == 0) {
-            s_red[threadIdx.x >> 6] = lower;
-            s_red[kBlock / 64 + (threadIdx.x >> 6)] = prev_all;
+        if (lane == 0) {
+            s_red[wave] = lower;
+            s_red[kBlock / 64 + wave] = prev_all;
         }
         mrl::lds_barrier();
         lower = 0;
@@ -672,21 +667,32 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_rollout(uint32_t n, float
             prev_all += s_red[kBlock / 64 + w];
         }
         base += prev_all;  // first episode index of this step
-        uint32_t running = lower;
-        if (block_total != 0) {  // uniform per workgroup
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {  // ascending world order
-                uint32_t total;
-                const uint32_t rank = block_rank(over[u], s_wave, total);
-                if (over[u]) {
-                    s[u] = fresh_state(base + running + rank);
-                    state[first + u * kBlock + threadIdx.x] = s[u];
-                }
-                running += total;
-                mrl::lds_barrier();
+        for (int u = 0; u < kUnroll; u++) {
+            const uint32_t i = first + u * kBlock + threadIdx.x;
+            if (i < last) {
+                action_out[i] = drawn[u];
+                if (!over[u]) state[i] = s[u];
+                reward[i] = 1.f;
+                done[i] = over[u] ? 1 : 0;
             }
         }
-        mrl::lds_barrier();  // s_red / s_wave are rewritten by the next step
+        if (block_total != 0) {  // uniform per workgroup
+            for (uint32_t e = lane; e < wave_total; e += 64u) {  // this wave's finished worlds, one per lane
+                const uint32_t entry = s_list[wave][e];
+                const float4 fresh = fresh_state(base + lower + (entry >> 16));
+                state[first + (entry & 0xffffu)] = fresh;
+                s_fresh[wave][e] = fresh;
+            }
+            uint32_t rounds_before = 0;  // (the slot is worked out again from the ballots, which live in scalar registers)
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t slot = rounds_before + (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
+                if (over[u]) s[u] = s_fresh[wave][slot];  // (written by this wave: DS operations of a wave execute in order)
+                rounds_before += (uint32_t)__popcll(votes[u]);
+            }
+        }
+        mrl::lds_barrier();  // s_red / s_votes / the lists are rewritten by the next step
     }
     if (last_block && num_steps > 0) {  // counter after the rollout: everybody's count of the last step
         const uint32_t epoch = epoch0 + num_steps - 1u;
@@ -995,7 +1001,11 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             // (the occupancy query can be one workgroup per CU too high, MI355X_MICROARCH.md "Residency and
             // cooperative launch": keep one per CU in hand near the edge; the cooperative launch is the check)
             const int usable = per_cu > 4 ? per_cu - 1 : per_cu;
-            sim->persistent_ok = !mrl::debug_get("cartpole.no_persistent", 0) && (uint64_t)sim->fused_grid <= (uint64_t)usable * (uint64_t)cus;
+            // Above kPersistentMaxWorlds one single-launch step per step is faster than the persistent launch (whose per-step
+            // hand-off reads every workgroup's count, flat): tools/cartpole_rollout_probe.py; cartpole.persistent_max moves the limit
+            const uint64_t persistent_max = (uint64_t)mrl::debug_get("cartpole.persistent_max", kPersistentMaxWorlds);
+            sim->persistent_ok = !mrl::debug_get("cartpole.no_persistent", 0) && (uint64_t)sim->fused_grid <= (uint64_t)usable * (uint64_t)cus &&
+                                 (uint64_t)num_worlds <= persistent_max;
             sim->ring = sim->arena.alloc<unsigned long long>((size_t)kRing * sim->fused_grid);
         }
         sim->reseed_shard(0, num_worlds, 0);
