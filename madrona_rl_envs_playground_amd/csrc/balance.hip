@@ -281,7 +281,8 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const int32_t *act
 
 __global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, const int32_t *action, int32_t *__restrict__ obs,
                                                                  float *__restrict__ reward, int32_t *__restrict__ done,
-                                                                 unsigned long long *status, uint32_t epoch, const uint32_t *episode_base,
+                                                                 uint32_t *status, unsigned long long *group_total, uint32_t epoch,
+                                                                 const uint32_t *episode_base,
                                                                  uint32_t *next_counter, uint32_t *__restrict__ reset_count, int32_t *action_out,
                                                                  uint64_t sample_seed, uint32_t sample_step, const mrl::HealTest heal,
                                                                  const mrl::DeviceCounter device_counter,
@@ -328,24 +329,25 @@ __global__ void __launch_bounds__(kBlock) mrl_balance_step_fused(uint32_t n, con
         }
     if (threadIdx.x == 0) mrl::publish_count(status, b, epoch, block_total);
     __syncthreads();  // the count is globally visible (vmcnt(0) in front of the barrier) before any row of this workgroup changes
-    if (threadIdx.x < 64 && (block_total != 0 || last_block)) {
-        const uint32_t before = mrl::wave_prefix_or_recount(status, b, epoch, heal, [&](uint32_t j) {
+    const bool needs_prefix = block_total != 0 || last_block;
+    if (threadIdx.x < 64) {  // (two levels: mrl::grouped_prefix, episode_scan.hpp; a workgroup that closes a group looks back whatever its count)
+        const uint32_t before = mrl::grouped_prefix(status, group_total, b, epoch, block_total, needs_prefix, heal, [&](uint32_t j) {
             return recount_chunk(n, action, obs, j, sampled, sample_seed, sample_step);
         });
         uint32_t lower_ranks = 0, all_counts = before + block_total;
-        if (fx.mail.num_ranks) {  // the last workgroup tells every rank the shard's total; the ranks below come first in the numbering
+        if (fx.mail.num_ranks && needs_prefix) {  // the last workgroup tells every rank the shard's total; the ranks below come first in the numbering
             lower_ranks = mrl::fused_exchange(fx, last_block, before + block_total, fx.mail.rank);
             if (last_block) all_counts = mrl::fused_exchange(fx, false, 0u, fx.mail.num_ranks);
         }
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && needs_prefix) {
             s_prefix = before;
             s_lower = lower_ranks;
             s_all = all_counts;
         }
     }
     mrl::lds_barrier();
-    const uint32_t own_before = block_total != 0 || last_block ? s_prefix : 0u;
-    const uint32_t before = own_before + (block_total != 0 || last_block ? s_lower : 0u);
+    const uint32_t own_before = needs_prefix ? s_prefix : 0u;
+    const uint32_t before = own_before + (needs_prefix ? s_lower : 0u);
     // (Storing the rows of the worlds that go on while the look-back is under way, and the fresh rows behind it, was measured:
     // 32.6 against 30.4 us per step at 1 M worlds -- the 28-byte rows of neighbouring worlds share cache lines, and writing a
     // line in two passes costs more than the 2 us of waiting.)
@@ -392,7 +394,8 @@ struct BalanceSim final : mrl_sim {
     void prepare_graph_capture(hipStream_t stream) override { launch_state.to_device(parity, epoch, stream); }
     unsigned long long *finished_mask = nullptr;  // one bit per world: the done flags, as each wave's ballot
     // single-launch step (mrl_balance_step_fused)
-    unsigned long long *status = nullptr;
+    uint32_t *status = nullptr;                 // 32-bit status words, and per 256 workgroups their total (mrl::grouped_prefix)
+    unsigned long long *group_total = nullptr;
     mrl::HealTest heal;
     uint32_t fused_grid = 0, epoch = 0;
     bool fused_step = false;
@@ -403,8 +406,8 @@ struct BalanceSim final : mrl_sim {
         epoch += 1;
         if (launch_state.device_mode) launch_state.advance(stream);
         hipLaunchKernelGGL(mrl_balance_step_fused, dim3(fused_grid), dim3(kBlock), 0, stream, num_worlds, actions ? actions : action, obs, reward,
-                           done, status, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed, sample_step, heal,
-                           launch_state.counter_args(counter), fx);
+                           done, status, group_total, epoch, counter + parity, counter + (parity ^ 1u), reset_count, action_out, seed, sample_step,
+                           heal, launch_state.counter_args(counter), fx);
         MRL_HIP(hipGetLastError());
         parity ^= 1u;
     }
@@ -557,7 +560,8 @@ mrl_sim *mrl::create_balance(int gpu_id, uint32_t num_worlds)
             const uint32_t blocks = (num_worlds + kFusedWorlds * kBlock - 1) / (kFusedWorlds * kBlock);
             if (blocks <= mrl::kMaxFusedBlocks) {
                 sim->fused_grid = blocks;
-                sim->status = sim->arena.alloc<unsigned long long>(blocks);
+                sim->status = sim->arena.alloc<uint32_t>(blocks);
+                sim->group_total = sim->arena.alloc<unsigned long long>((blocks + mrl::kGroup - 1) / mrl::kGroup);
                 sim->heal.mod = (uint32_t)mrl::debug_get("fused_heal_test", 0);
                 sim->heal.seen = sim->arena.alloc<uint32_t>(blocks);
                 sim->fused_step = mrl::debug_get("fused_step", 0) != 2;  // 0 / 1: one launch (every row written once), 2: the two-launch pair

@@ -382,19 +382,7 @@ __device__ __forceinline__ uint32_t recount_chunk(uint32_t n, const float4 *stat
 // workgroup that does not see the count reads the state as the step's input).  The finished worlds of a wave -- a dozen
 // of its 256 under a random policy -- are re-seeded by as many lanes in ONE pass over a list in LDS (the seed hash is
 // ~150 dependent instructions; per round it would run four times for three lanes each).
-// The look-back has two levels: a workgroup's status word (32 bits) and, per GROUP of 256 consecutive workgroups, the
-// group's total, published by the group's last workgroup once its own look-back over the other 255 is done.  A workgroup
-// needs the words of the lower workgroups of its own group (up to four per lane) and the totals of the lower groups (up to
-// sixteen in all).  Batches of up to 262144 worlds are one group: one hand-off through memory, ~1.5 us under the other
-// waves' traffic; larger ones pay a second for the group totals.  (Round 4 measured the flat form first -- every workgroup
-// reading all lower status words, up to sixteen per lane at 1 M worlds: the 4 KB those words occupy are one hot spot that
-// a million uncached loads queue on, 3-5 us per look-back, profiles/r04_e_cartpole_fused_timeline_flat_lookback.txt --
-// and asking for the words BEFORE the expensive half: they come back stale, the workgroups around publish at the same
-// moment, and the second asking queues behind the first.)  A group total that does not appear is replaced by its 256 status
-// words, a status word that does not appear by a recount: nothing waits on another workgroup.
-constexpr uint32_t kGroup = 256;
-constexpr int kGroupWords = kGroup / 64;  // status words per lane
-
+// (the look-back has two levels: mrl::grouped_prefix, episode_scan.hpp)
 template <int V>
 __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, const int32_t *action,  // (no __restrict__: may be action_out)
                                                                   float4 *__restrict__ state, float *__restrict__ reward,
@@ -485,9 +473,6 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     // the count leaves ~30 instructions after the state has come in and travels while the expensive half runs
     if (wave == 0 && lane == 0) mrl::publish_count(status, b, epoch, block_total);
     const bool needs_prefix = block_total != 0 || last_block;  // uniform per workgroup
-    const uint32_t group = b / kGroup, group_first = group * kGroup;
-    const bool closes_group = b + 1 == group_first + kGroup;   // the group's last workgroup publishes the group's total
-    const bool looks_back = wave == 0 && (needs_prefix || closes_group);
     CP_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
     // (sin, cos, the accelerations: ~2 us of issue per SIMD at 1 M worlds)
@@ -507,21 +492,10 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mrl::lds_barrier();
     CP_STAMP(4);
-    if (looks_back) {  // (wave 0) before its own stores: a load would sit out their acknowledgement
-        auto recount = [&](uint32_t j) { return recount_chunk<V>(n, state, j); };
-        uint32_t lower[kGroupWords];
-        unsigned long long lower_groups[1];
-        mrl::lookback_issue<kGroupWords>(status, group_first, b, lower);
-        mrl::lookback_issue<1>(group_total, 0, needs_prefix ? group : 0u, lower_groups);
-        const uint32_t in_group = mrl::wave_sum(mrl::lookback_finish<kGroupWords>(status, group_first, b, epoch, heal, lower, recount));
-        if (closes_group && lane == 0) mrl::publish_count(group_total, group, epoch, in_group + block_total);
+    if (wave == 0) {  // before its own stores: a load would sit out their acknowledgement
+        uint32_t before = mrl::grouped_prefix(status, group_total, b, epoch, block_total, needs_prefix, heal,
+                                              [&](uint32_t j) { return recount_chunk<V>(n, state, j); });
         if (needs_prefix) {
-            auto regroup = [&](uint32_t g) {  // a group total that has not appeared: the group's 256 words instead
-                uint32_t words[kGroupWords];
-                mrl::lookback_issue<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, words);
-                return mrl::wave_sum(mrl::lookback_finish<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, epoch, heal, words, recount));
-            };
-            uint32_t before = in_group + mrl::wave_sum(mrl::lookback_finish<1>(group_total, 0, group, epoch, mrl::HealTest{}, lower_groups, regroup));
             if (fx.mail.num_ranks) {
                 // a shard of a larger batch: the last workgroup knows the shard's total and tells every rank; the ranks
                 // below this one come first in the numbering, and the counter moves on by the sum over all ranks
@@ -972,7 +946,7 @@ mrl_sim *mrl::create_cartpole(int gpu_id, uint32_t num_worlds)
             if (blocks <= mrl::kMaxFusedBlocks) {
                 sim->fused_grid = blocks;
                 sim->status = sim->arena.alloc<uint32_t>(blocks);
-                sim->group_total = sim->arena.alloc<unsigned long long>((blocks + kGroup - 1) / kGroup);
+                sim->group_total = sim->arena.alloc<unsigned long long>((blocks + mrl::kGroup - 1) / mrl::kGroup);
 #ifdef MRL_DIAG
                 if (mrl::debug_get("stamps", 0)) sim->stamps = sim->arena.alloc<unsigned long long>((size_t)blocks * (kBlock / 64) * 8);
 #endif

@@ -437,4 +437,44 @@ __device__ __forceinline__ uint32_t wave_prefix_or_recount(const Word *status, u
     return wave_sum(before);
 }
 
+// ---- the look-back in two levels (Cartpole, balance beam: up to 4096 workgroups) ----
+// A workgroup's status word (32 bits) and, per GROUP of 256 consecutive workgroups, the group's total, published by the
+// group's last workgroup once its own look-back over the other 255 is done.  A workgroup needs the words of the lower
+// workgroups of its own group (up to four per lane) and the totals of the lower groups (up to sixteen in all).  Batches of
+// up to 256 workgroups are one group: one hand-off through memory, ~1.5 us under the other waves' traffic; larger ones pay
+// a second for the group totals.  (Round 4 measured the flat form at 1024 workgroups -- every workgroup reading all lower
+// status words, up to sixteen per lane: the 4 KB those words occupy are one hot spot that a million uncached loads queue
+// on, 3-5 us per look-back, profiles/r04_e_cartpole_fused_timeline_flat_lookback.txt -- and asking for the words BEFORE
+// the work that hides their latency: they come back stale, the workgroups around publish at the same moment, and the
+// second asking queues behind the first.)  A group total that does not appear is replaced by its 256 status words, a
+// status word that does not appear by a recount: nothing waits on another workgroup.
+constexpr uint32_t kGroup = 256;
+constexpr int kGroupWords = kGroup / 64;  // status words per lane
+
+// Called by ONE wave of workgroup `block`, which has published its own count, with wave-uniform arguments.  Publishes the
+// group's total if this workgroup closes a group; returns to every lane the counts of workgroups [0, block) summed up
+// (0 unless needs_prefix).
+template <typename Recount>
+__device__ __forceinline__ uint32_t grouped_prefix(const uint32_t *status, unsigned long long *group_total, uint32_t block, uint32_t epoch,
+                                                   uint32_t block_total, bool needs_prefix, const HealTest &heal, Recount &&recount)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t group = block / kGroup, group_first = group * kGroup;
+    const bool closes_group = block + 1 == group_first + kGroup;  // the group's last workgroup publishes the group's total
+    if (!needs_prefix && !closes_group) return 0;
+    uint32_t lower[kGroupWords];
+    unsigned long long lower_groups[1];
+    lookback_issue<kGroupWords>(status, group_first, block, lower);
+    lookback_issue<1>(group_total, 0, needs_prefix ? group : 0u, lower_groups);
+    const uint32_t in_group = wave_sum(lookback_finish<kGroupWords>(status, group_first, block, epoch, heal, lower, recount));
+    if (closes_group && lane == 0) publish_count(group_total, group, epoch, in_group + block_total);
+    if (!needs_prefix) return 0;
+    auto regroup = [&](uint32_t g) {  // a group total that has not appeared: the group's 256 words instead
+        uint32_t words[kGroupWords];
+        lookback_issue<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, words);
+        return wave_sum(lookback_finish<kGroupWords>(status, g * kGroup, g * kGroup + kGroup, epoch, heal, words, recount));
+    };
+    return in_group + wave_sum(lookback_finish<1>(group_total, 0, group, epoch, HealTest{}, lower_groups, regroup));
+}
+
 }  // namespace mrl
