@@ -369,8 +369,27 @@ __device__ __forceinline__ uint32_t byte_at(const uint32_t (&r)[kRecordWords], u
 // kFresh: the record is a game that deal_new_game has just written (full hands, 40 cards in the deck, all
 // tokens, nothing played, discarded or hinted) -- only the ten dealt cards are read, the rest folds to
 // constants.  The re-deal launch is a serial chain on a few lanes per wave, so its length is what counts.
-template <bool kFresh>
-__device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t *enc, uint32_t agent)
+// `early(stage)`: the single-launch step lets another wave store whole 128-byte lines of the row while this one goes on
+// encoding.  Stage 1: words 0..3 of the bit vector are in LDS (bits 0..127: the partner's hand, the short-hand flags, the
+// first bit of the deck -- line 0).  Stage 2: words 12..19 are (bits 384..639, card knowledge only whatever the shift of
+// 0..5 bits: lines 3 and 4); with a hand-off to make, the knowledge section is therefore encoded before the discards and
+// the last action, which it does not depend on.
+struct NoEarlyLine {
+    static constexpr bool kActive = false;
+    __device__ __forceinline__ void operator()(uint32_t) const {}
+};
+struct EarlyLineFlag {  // raises a flag in LDS behind the words (LDS operations of a wave complete in order)
+    static constexpr bool kActive = true;
+    uint32_t *flag;
+    uint32_t lane;
+    __device__ __forceinline__ void operator()(uint32_t stage) const
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(flag, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+template <bool kFresh, typename EarlyLine = NoEarlyLine>
+__device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t *enc, uint32_t agent, const EarlyLine &early = EarlyLine())
 {
     using namespace full_game;
     uint32_t r[kRecordWords];
@@ -413,9 +432,16 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
     const uint32_t info_now = min(info, 13u);
     const uint32_t excess = info_now > 8u ? info_now - 8u : 0u;
     orbits(lo, kOffInfo, 13, ones(info_now));
+    if constexpr (EarlyLine::kActive) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) enc[w] = lo[w];
+        early(1u);
+    }
+    const uint32_t sh = 8u + excess;  // 8..13: the relative part goes up by 200 + excess = 6 words + sh bits
 
     // everything below is placed relative to bit 200 + excess
     orbits(hi, 0, 3, ones(kFresh ? 3u : min(byte_at(r, R_LIFE), 3u)));
+    auto discards_and_last_action = [&]() {
     // discards (:137-156)
 #pragma unroll
     for (uint32_t c = 0; c < (kFresh ? 0u : kK); c++) {
@@ -449,6 +475,8 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
         orbits(hi, kRelLast + 53, 2,
                move == MV_PLAY ? (byte_at(r, R_LM_SCORED) ? 1u : 0u) | (byte_at(r, R_LM_INFOTOK) ? 2u : 0u) : 0u);
     }
+    };
+    if constexpr (!EarlyLine::kActive) discards_and_last_action();
     // card knowledge (:291-331): own hand first, then the partner's
 #pragma unroll
     for (uint32_t i = 0; i < 2; i++) {
@@ -462,10 +490,17 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
             const uint32_t base = kRelKnow + (i * kHand + c) * (kBpc + kK + kRk);
             orbits(hi, base, kBpc, (have && ((plaus >> i) & 1u)) ? ones(kBpc) : 0u);  // sim.cpp:311: bit <i>, not bit <v>
             uint32_t kr = 0;
-            kr |= kcb < kK ? 1u << kcb : 0u;          // 0xFF = unknown
-            kr |= kkb < kRk ? 1u << (kK + kkb) : 0u;
+            kr |= kcb < kK ? 1u << (kcb & 31u) : 0u;  // 0xFF = unknown
+            kr |= kkb < kRk ? 1u << ((kK + kkb) & 31u) : 0u;
             orbits(hi, base + kBpc, kK + kRk, have ? kr : 0u);
         }
+    }
+    if constexpr (EarlyLine::kActive) {
+        static_assert(5u * 32u >= kRelKnow && 14u * 32u <= kRelOwnHand, "hi[5..13], which words 12..19 are made of, hold card knowledge only");
+#pragma unroll
+        for (int w = 6; w < 14; w++) enc[6 + w] = __builtin_amdgcn_alignbit(hi[w], hi[w - 1], 32u - sh);
+        early(2u);
+        discards_and_last_action();
     }
     // state tail: own hand (:343-365)
 #pragma unroll
@@ -489,7 +524,6 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
     legal |= info > 0 ? hints : 0u;
 
     // merge: words 0..6 from lo, the relative part shifted up by 200 + excess = 6 words + (8 + excess) bits
-    const uint32_t sh = 8u + excess;  // 8..13
     uint32_t out[25];
 #pragma unroll
     for (int w = 0; w < 6; w++) out[w] = lo[w];
@@ -497,7 +531,8 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
 #pragma unroll
     for (int w = 1; w < kHiWords; w++) out[6 + w] = __builtin_amdgcn_alignbit(hi[w], hi[w - 1], 32u - sh);
 #pragma unroll
-    for (int w = 0; w < 25; w++) enc[w] = out[w];
+    for (int w = 0; w < 25; w++)
+        if (!EarlyLine::kActive || (w >= 4 && !(w >= 12 && w < 20))) enc[w] = out[w];
     enc[25] = legal & 0xFFFFFu;
     enc[26] = excess;
 }
@@ -958,32 +993,89 @@ __device__ __forceinline__ WaveLds wave_lds(uint8_t *smem, uint32_t wib)
     return WaveLds{base, reinterpret_cast<uint32_t *>(base + kWorldsPerWave * kRecStride)};
 }
 
-// Phase B for a wave's movers: the 56 chunks of an agent block times the wave's worlds, 64 chunks per store -- 28 full-width
-// stores for 32 worlds.  Chunk f of that run belongs to world f / 56 (a multiply-shift) and is chunk f % 56 of its block.
+// Phase B for a wave's movers.  An agent block is seven 128-byte lines of eight chunks, and a wave store is eight lines:
+// lane = (world k = lane / 8 of an octet of worlds, chunk c8 = lane % 8 of a line), so that everything that depends on
+// the lane alone -- which half of which bit-vector word, the byte offset inside the octet -- is worked out once, a
+// line is an immediate offset of the LDS read and of the store, and a round is  shift, 4 x (bfe, mul, and), store:
+// 28 stores for 32 worlds as before, each of eight whole lines, on a quarter of the instructions.  (The run-length form
+// it replaces -- 64 consecutive chunks per store, world = f / 56 and chunk = f % 56 by multiply-shift, the kind of chunk
+// chosen by selects -- issued 70 VALU instructions per store; two waves of a SIMD then take 0.22 us per pair of stores,
+// which was what phase B took.)  Lines 0..5 are state chunks 0..47; line 6 is state chunk 48, the five mask chunks
+// and two chunks of padding.  kV == 2: the full game's encoder never sets a bit past state_bits + shift and chunk 48
+// reads bits 768..783 only, so the `keep` mask of chunk_bytes folds away; the other variants keep it.
+// lines [kFirst, kLast) of the movers' blocks (the single-launch step hands line 0 over early, see there)
+template <int kV, uint32_t kFirst, uint32_t kLast>
+__device__ __forceinline__ void expand_lines(const HanabiParams &p, const WaveLds &l, uint32_t nw, uint32_t overs, uint32_t movers,
+                                             __amdgpu_buffer_rsrc_t out, uint32_t lane)
+{
+    constexpr uint32_t kLines = kAgentBlock / 128u;  // 7
+    static_assert(kStateChunks == 8 * (kLines - 1) + 1 && kMaskChunks == 5, "line 6 = state chunk 48, five mask chunks, padding");
+    static_assert(kFirst < kLast && kLast <= kLines, "a range of lines");
+    constexpr bool kTail = kLast == kLines;                    // line 6 is among them
+    constexpr uint32_t kPlain = kTail ? kLines - 1u : kLast;   // lines [kFirst, kPlain) are eight state chunks each
+    constexpr uint32_t kDropped = 0x40000000u;  // past any descriptor, and the line offsets added to it do not wrap
+    const uint32_t k = lane >> 3, c8 = lane & 7u;
+    const uint32_t half = (c8 & 1u) * 16u;
+    const uint32_t lane_at = k * kWorldBlock + c8 * 16u;
+    // line 6, by lane: chunk 48 of the state (c8 == 0), mask chunk c8 - 1 (c8 1..5), padding (6, 7)
+    const bool tail = c8 == 0u;
+    const uint32_t legal_at = 4u * min(c8 - 1u, 5u), legal_keep = (c8 - 1u) < (uint32_t)kMaskChunks ? 0xFu : 0u;
+    const uint32_t stride = tail ? 4u : 1u, nib = tail ? 0xFu : 1u;
+    const uint32_t octets = (nw + 7u) >> 3;  // wave-uniform
+    struct Words {
+        uint32_t w[kLines], legal, shift;
+    };
+    auto request = [&](uint32_t o) {
+        const uint32_t *e = l.enc + min(o * 8u + k, (uint32_t)kWorldsPerWave - 1u) * 2 * kEncWords;
+        Words q;
+#pragma unroll
+        for (uint32_t line = kFirst; line < kPlain; line++) q.w[line] = e[line * 4u + (c8 >> 1)];
+        if constexpr (kTail) {
+            q.w[kLines - 1] = e[24];
+            q.legal = e[25];
+        }
+        if constexpr (kV != 2) q.shift = e[26];
+        return q;
+    };
+    Words next = request(0);
+#pragma unroll 1
+    for (uint32_t o = 0; o < octets; o++) {
+        const Words cur = next;
+        next = request(o + 1u);  // requested before this octet's arithmetic
+        const uint32_t r = o * 8u + k;
+        const bool skip = r >= nw || ((overs >> r) & 1u);  // a finished world's rows come from the re-deal
+        const uint32_t agent = (movers >> r) & 1u;
+        const uint32_t at = skip ? kDropped : o * (8u * kWorldBlock) + lane_at + agent * kAgentBlock;
+        auto piece_of = [&](uint32_t word, uint32_t line) {
+            const uint32_t piece = (word >> half) & 0xFFFFu;
+            if constexpr (kV == 2) {
+                return piece;
+            } else {  // what the shifted encoding pushes past the row's end is dropped
+                const int32_t limit = (int32_t)min(p.state_bits + cur.shift, (uint32_t)MRL_HANABI_STATE_SIZE) - (int32_t)(c8 * 16u);
+                const int32_t room = limit - (int32_t)(line * 128u);
+                return piece & ((1u << (uint32_t)min(max(room, 0), 16)) - 1u);
+            }
+        };
+#pragma unroll
+        for (uint32_t line = kFirst; line < kPlain; line++) {
+            const uint32_t piece = piece_of(cur.w[line], line);
+            row_store(out, at + line * 128u,
+                      make_uint4(spread4(piece & 0xFu), spread4((piece >> 4) & 0xFu), spread4((piece >> 8) & 0xFu), spread4(piece >> 12)));
+        }
+        if constexpr (kTail) {
+            // (chunk 48 sits in the low half of word 24: `half` is 0 for the lane that takes it)
+            const uint32_t src = tail ? piece_of(cur.w[kLines - 1], kLines - 1) : (cur.legal >> legal_at) & legal_keep;
+            row_store(out, at + (kLines - 1) * 128u,
+                      make_uint4(spread4(src & nib), spread4((src >> stride) & nib), spread4((src >> (2u * stride)) & nib),
+                                 spread4((src >> (3u * stride)) & nib)));
+        }
+    }
+}
+template <int kV>
 __device__ __forceinline__ void expand_movers(const HanabiParams &p, const WaveLds &l, uint32_t nw, uint32_t overs, uint32_t movers,
                                               __amdgpu_buffer_rsrc_t out, uint32_t lane)
 {
-    const uint32_t total = nw * kAgentChunks;  // <= 1792
-    const uint32_t rounds = (total + kWave - 1u) / kWave;  // wave-uniform: the loop runs on a scalar counter
-    // (f / 56 by multiply-shift, exact for f < 4096; lanes behind the run read world 31's words and store nothing)
-    auto source_of = [&](uint32_t f) {
-        const uint32_t r = min((f * 2341u) >> 17, (uint32_t)kWorldsPerWave - 1u);
-        return chunk_source(l.enc + r * 2 * kEncWords, f - r * kAgentChunks);
-    };
-    ChunkSource next = source_of(lane);
-#pragma unroll 2
-    for (uint32_t i = 0; i < rounds; i++) {
-        const uint32_t f = i * kWave + lane;
-        const ChunkSource cur = next;
-        next = source_of(f + kWave);  // requested before this round's arithmetic
-        const uint32_t r = min((f * 2341u) >> 17, (uint32_t)kWorldsPerWave - 1u);
-        const uint32_t ch = f - r * kAgentChunks;
-        const uint4 v = chunk_bytes(p, cur, ch);
-        const uint32_t agent = (movers >> r) & 1u;
-        const bool skip = f >= total || ((overs >> r) & 1u);  // a finished world's rows come from the re-deal
-        const uint32_t at = skip ? 0xFFFFFFF0u : r * kWorldBlock + agent * kAgentBlock + ch * 16u;  // out of range = dropped by the descriptor
-        row_store(out, at, v);
-    }
+    expand_lines<kV, 0u, (uint32_t)kAgentBlock / 128u>(p, l, nw, overs, movers, out, lane);
 }
 
 // The wave's records, HBM <-> LDS.  A wave's worlds are one contiguous run of 176-byte records (32 worlds = 44 whole
@@ -1111,7 +1203,7 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
         {
             const uint32_t w0s = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
             const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0s * kWorldBlock, nw * kWorldBlock);
-            if (!ABLATED(2)) expand_movers(p, l, nw, overs, movers, out, lane);
+            if (!ABLATED(2)) expand_movers<kV>(p, l, nw, (uint32_t)overs, (uint32_t)movers, out, lane);
         }
         STAMP(5);
         store_records(p, l, w0, nw, lane);  // (a finished world's record is dealt anew by the re-deal launch that follows)
@@ -1346,6 +1438,19 @@ __device__ __forceinline__ void store_fresh_rows(const HanabiParams &p, const Wa
     }
 }
 
+// Hand-offs between the waves of a workgroup through counters in LDS instead of barriers: a counter is raised after the LDS
+// traffic it announces.
+__device__ __forceinline__ void flag_wait(uint32_t *flag, uint32_t at_least)
+{
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < at_least) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void flag_raise(uint32_t *flag, uint32_t lane)  // by one: every wave of a job raises it once per step
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // The whole step in ONE launch (mrl_step on one GPU, batches of one sub-block per workgroup: up to 262144 worlds):
 // transition, look-back over the lower workgroups' finished counts instead of a kernel boundary, re-deal.  Workgroup
 // b owns worlds [256 b, 256 b + 256) and has NINE waves: eight step 32 worlds each exactly like mrl_hanabi_step
@@ -1361,6 +1466,13 @@ __device__ __forceinline__ void store_fresh_rows(const HanabiParams &p, const Wa
 // The two-launch pair stays for the sharded path (the episode base comes from the other ranks in between) and for
 // larger batches.
 constexpr int kFusedBlock = kBlock + kWave;
+// Measurement variants (same sources, other flags: tools/hanabi_ab.sh).  0: every row store waits for the whole encode; 1: the
+// rows' first line is stored by the partner wave while its leader still encodes; 2: lines 3 and 4 (card knowledge) as well.
+// One box, 65536 worlds, us per step: 18.05-18.10 / 17.22-17.23 / 17.04-17.15 (profiles/r04_aa_hanabi_early_lines_ab.txt).
+// (A waiting wave that sleeps 0.6 us before it starts polling its leader's counter changed nothing: r04_z.)
+#ifndef MRL_HANABI_EARLY_LINE
+#define MRL_HANABI_EARLY_LINE 2
+#endif
 
 // (nine waves = three on one of the four SIMDs: amdgpu_waves_per_eu(3) holds the kernel to 168 VGPRs)
 template <int kV>
@@ -1375,6 +1487,9 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     __shared__ __attribute__((aligned(16))) uint8_t s_scratch[kWorldsPerWave * kRecStride];  // the scan wave's copy of another workgroup's records (healing)
     __shared__ uint32_t s_counts[kWavesPerBlock];
     __shared__ uint32_t s_ready;  // 1: the workgroup's count is globally visible, records may be overwritten; 2: the fresh games are in LDS as well
+    __shared__ uint32_t s_moved, s_encoded;  // leaders past the transition (counts, ballots in LDS) / past the encode (bit vectors in LDS)
+    __shared__ uint32_t s_leader_done[kWavesPerBlock];  // per leader: its own and its partner's bit vectors are in LDS
+    __shared__ uint32_t s_line0[kWavesPerBlock];        // per leader: ... their first four words are (the rows' first lines can go)
     __shared__ uint8_t s_fin[kWavesPerBlock][kWorldsPerWave];
     __shared__ uint32_t s_overs[kWavesPerBlock], s_movers[kWavesPerBlock];  // per wave of worlds: finished / next mover is agent 1
     // the records are requested with the kernel's first instructions, from the preloaded arguments alone
@@ -1397,14 +1512,31 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     const uint32_t N = p.num_worlds;
     const bool last_block = bid == gridDim.x - 1;
     if (scan_wave || heal_mod) device_counter.apply(episode_base, next_counter, epoch);  // (the launch state may live in device memory: common.hpp)
-    if (threadIdx.x == 0) s_ready = 0u;
+    if (threadIdx.x == 0) {
+        s_ready = 0u;
+        s_moved = 0u;
+        s_encoded = 0u;
+    }
+    if (threadIdx.x < (uint32_t)kWavesPerBlock) {
+        s_leader_done[threadIdx.x] = 0u;
+        s_line0[threadIdx.x] = 0u;
+    }
     if (heal_mod) mrl::heal_test_delay(heal, bid, gridDim.x, epoch);  // test hook only (uniform branch on a preloaded argument)
+    const bool paired = pair_stride != 0;
+    const uint32_t leaders = paired ? (uint32_t)kWavesPerBlock / 2u : (uint32_t)kWavesPerBlock;
 
     if (scan_wave) {
         // ================= the scan wave =================
+        // The count of finishing worlds is known as soon as the leaders are past the TRANSITION, well before their encode is
+        // through: published and looked back for then, the hand-off through memory runs while the fabric is idle -- under the
+        // row stores every poll is a round trip of 2 us and a workgroup that publishes late holds up all higher ones
+        // (profiles/r04_v_hanabi_fused_timeline.txt: prefix known at 6.2 us in the median, 11.3 at p90, 13.2 at worst).
         const uint32_t base = *episode_base;  // requested now, needed after the look-back
-        if (pair_stride != 0) mrl::lds_barrier();  // (the stepping waves' hand-over of their records to the leaders)
-        mrl::lds_barrier();                         // phase A is through: s_counts and s_fin are there
+        mrl::lds_barrier();  // the counters above are zero (and the stepping waves' records in LDS)
+        flag_wait(&s_moved, leaders);  // the transition is through: s_counts and s_fin are there
+        // (look-back and re-deal are a serial chain that two streaming waves share a SIMD with; not while it polls for the
+        // leaders, one of which shares its SIMD: a polling wave of higher priority took 0.5 us out of that leader's transition)
+        __builtin_amdgcn_s_setprio(3);
         FSTAMP_SCAN(0);
         uint32_t start_of[kWavesPerBlock + 1];
         start_of[0] = 0;
@@ -1431,6 +1563,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             *reset_count = before + block_total;
             *next_counter = base + all_counts;
         }
+        flag_wait(&s_encoded, leaders);  // the leaders have written their last bit vector: the finished worlds' slots are free
         deal_finished_worlds<kV>(p, [&](uint32_t wv) { return wave_lds(smem, wv); }, s_fin, start_of, base + lower_ranks + before, lane);
         if (lane == 0) __hip_atomic_store(&s_ready, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         FSTAMP_SCAN(2);
@@ -1445,7 +1578,6 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     // two waves a SIMD gets when a workgroup's waves are dealt round-robin; 1 = waves (2k, 2k + 1); 0 = every wave for itself.
     const WaveLds l = wave_lds(smem, wib);
     FSTAMP(0);
-    const bool paired = pair_stride != 0;
     const bool leader = !paired || (pair_stride == 4 ? wib < 4 : (wib & 1u) == 0);
     const uint32_t half = paired ? lane >> 5 : 0u, idx = paired ? lane & 31u : lane;
     const uint32_t slot = wib + half * pair_stride;             // whose worlds this lane steps in phase A
@@ -1458,29 +1590,22 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     }
     place_records(l, nw, lane, pending);
     FSTAMP(1);
-    if (paired) mrl::lds_barrier();  // the partner's records are in LDS too
-    else wave_lds_sync();
+    mrl::lds_barrier();  // the partner's records are in LDS too, and the hand-off counters are zero
 
     // ---- phase A: act, encode the next mover ----
+    // Two hand-offs, both through counters in LDS (no barrier: nobody waits for more than it needs).  Behind the TRANSITION
+    // the finished worlds go to the scan wave, which publishes and looks back while the leaders encode; behind the ENCODE the
+    // bit vectors go to the partner (per leader) and the finished worlds' slots to the scan wave's re-deal.
     if (leader) {
         const WaveLds ls = wave_lds(smem, slot);
         bool over = false, next_is_1 = false;
+        Moved m{false, 0.f};
+        uint8_t *rec = ls.rec + idx * kRecStride;
+        const uint32_t world = a_w0 + idx;
         if (idx < a_nw) {
-            uint8_t *rec = ls.rec + idx * kRecStride;
-            const uint32_t world = a_w0 + idx;
-            const Moved m = move_world<kV>(p, rec, world, act0, act1, true);
-            const uint32_t next = rec[R_CUR] & 1u;
-            next_is_1 = next != 0;
-            encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+            m = move_world<kV>(p, rec, world, act0, act1, true);
             over = m.over;
-            // (a finished world's next episode opens with agent 0 to move, sim.cpp:446-532: written here, so that every
-            // ACTIVE word has one writer -- two waves' stores to one address are ordered by nothing short of a wait for the first)
-            const uint32_t mover = over ? 0u : next;
-            p.active[(size_t)mover * N + world] = 1;
-            p.active[(size_t)(mover ^ 1u) * N + world] = 0;
-            p.reward[world] = m.reward;
-            p.reward[(size_t)N + world] = m.reward;
-            p.done[world] = over ? 1 : 0;
+            next_is_1 = (rec[R_CUR] & 1u) != 0;
         }
         const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
         // the half's share of the ballots (a wave for itself: the whole ballot is its "low half", idx = lane < 32 worlds)
@@ -1491,9 +1616,66 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             s_overs[slot] = my_overs;
             s_movers[slot] = my_movers;
         }
+        flag_raise(&s_moved, lane);
+        FSTAMP(4);
+        if (idx < a_nw) {
+            const uint32_t next = next_is_1 ? 1u : 0u;
+            if constexpr (kV == 2 && MRL_HANABI_EARLY_LINE) {
+                if (paired) {
+                    // the rows' first line goes to the partner as soon as its 128 bits are in LDS (lane 0 is a world whenever
+                    // the wave has any; LDS operations of a wave complete in order, so the flag follows the words)
+                    encode_agent_full_t<false>(rec, ls.enc + idx * 2 * kEncWords, next, EarlyLineFlag{&s_line0[wib], lane});
+                } else {
+                    encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                }
+            } else {
+                encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+            }
+            // (a finished world's next episode opens with agent 0 to move, sim.cpp:446-532: written here, so that every
+            // ACTIVE word has one writer -- two waves' stores to one address are ordered by nothing short of a wait for the first)
+            const uint32_t mover = over ? 0u : next;
+            p.active[(size_t)mover * N + world] = 1;
+            p.active[(size_t)(mover ^ 1u) * N + world] = 0;
+            p.reward[world] = m.reward;
+            p.reward[(size_t)N + world] = m.reward;
+            p.done[world] = over ? 1 : 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __hip_atomic_store(&s_leader_done[wib], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_encoded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        FSTAMP(2);
+    } else {
+        FSTAMP(2);
+        const uint32_t lslot = wib - pair_stride;  // its leader
+        if constexpr (kV == 2 && MRL_HANABI_EARLY_LINE) {
+            // While the leader encodes on: the first line of the rows of its worlds and of this wave's, 16 stores -- the fabric
+            // has something to do a microsecond before phase A is through.
+            const uint32_t l_w0 = bid * kWorldsPerBlock + lslot * kWorldsPerWave;
+            const uint32_t l_nw = l_w0 < N ? min((uint32_t)kWorldsPerWave, N - l_w0) : 0u;
+            if (l_nw != 0) {
+                flag_wait(&s_line0[lslot], 1u);
+                // (the SIMD's arbiter prefers the older wave, and the leader hardly ever stalls: without this the partner's sixteen
+                // stores were issued when the leader was through, profiles/r04_x_hanabi_fused_timeline.txt)
+                __builtin_amdgcn_s_setprio(2);
+                expand_lines<kV, 0u, 1u>(p, wave_lds(smem, lslot), l_nw, s_overs[lslot], s_movers[lslot],
+                                         row_resource(p.rows + (size_t)l_w0 * kWorldBlock, l_nw * kWorldBlock), lane);
+                expand_lines<kV, 0u, 1u>(p, l, nw, s_overs[wib], s_movers[wib], row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock), lane);
+                __builtin_amdgcn_s_setprio(0);
+                FSTAMP(4);
+#if MRL_HANABI_EARLY_LINE >= 2
+                flag_wait(&s_line0[lslot], 2u);  // lines 3 and 4: card knowledge
+                __builtin_amdgcn_s_setprio(2);
+                expand_lines<kV, 3u, 5u>(p, wave_lds(smem, lslot), l_nw, s_overs[lslot], s_movers[lslot],
+                                         row_resource(p.rows + (size_t)l_w0 * kWorldBlock, l_nw * kWorldBlock), lane);
+                expand_lines<kV, 3u, 5u>(p, l, nw, s_overs[wib], s_movers[wib], row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock), lane);
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+        }
+        flag_wait(&s_leader_done[lslot], 1u);  // its leader's encode of this wave's worlds (and its ballots) is in LDS
     }
-    FSTAMP(2);
-    mrl::lds_barrier();  // hands the finished worlds to the scan wave (and a partner's ballots back to it)
     FSTAMP(3);
     const unsigned long long overs = s_overs[wib], movers = s_movers[wib];
     const uint32_t mine = (uint32_t)__popcll(overs);
@@ -1501,7 +1683,16 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
     // ---- phase B: the movers' rows of the worlds that go on ----
     {
         const __amdgpu_buffer_rsrc_t out = row_resource(p.rows + (size_t)w0 * kWorldBlock, nw * kWorldBlock);
-        expand_movers(p, l, nw, overs, movers, out, lane);
+        if (kV == 2 && MRL_HANABI_EARLY_LINE && paired) {
+#if MRL_HANABI_EARLY_LINE >= 2
+            expand_lines<kV, 1u, 3u>(p, l, nw, (uint32_t)overs, (uint32_t)movers, out, lane);
+            expand_lines<kV, 5u, 7u>(p, l, nw, (uint32_t)overs, (uint32_t)movers, out, lane);
+#else
+            expand_lines<kV, 1u, 7u>(p, l, nw, (uint32_t)overs, (uint32_t)movers, out, lane);
+#endif
+        } else {
+            expand_movers<kV>(p, l, nw, (uint32_t)overs, (uint32_t)movers, out, lane);
+        }
     }
     FSTAMP(5);
     // ---- rows of this wave's finished worlds, dealt anew by the scan wave meanwhile; then all 32 records at once ----
@@ -1558,16 +1749,6 @@ __device__ __forceinline__ WaveLds rollout_lds(uint8_t *smem, uint32_t slot, uin
     return WaveLds{smem + slot * kSlotRecBytes,
                    reinterpret_cast<uint32_t *>(smem + kWavesPerBlock * kSlotRecBytes + (buf * kWavesPerBlock + slot) * kSlotEncBytes)};
 }
-__device__ __forceinline__ void flag_wait(uint32_t *flag, uint32_t at_least)
-{
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < at_least) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void flag_raise(uint32_t *flag, uint32_t lane)  // by one: every wave of a job raises it once per step
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 template <int kV>
 __global__ void __launch_bounds__(kRolloutBlock) __attribute__((amdgpu_waves_per_eu(4)))
@@ -1577,7 +1758,7 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
     __shared__ __attribute__((aligned(16))) uint8_t smem[kRolloutLdsBytes];
     __shared__ uint32_t s_counts[2][kWavesPerBlock], s_overs[2][kWavesPerBlock], s_movers[2][kWavesPerBlock];  // by step parity, like the bit vectors
     __shared__ uint8_t s_fin[2][kWavesPerBlock][kWorldsPerWave];
-    __shared__ uint32_t s_a_done, s_dealt, s_b_done;
+    __shared__ uint32_t s_a_done, s_dealt, s_b_done, s_a_moved;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     HanabiParams p = p0;
@@ -1587,6 +1768,7 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
         s_a_done = 0u;
         s_dealt = 0u;
         s_b_done = 0u;
+        s_a_moved = 0u;
     }
     const uint32_t b_slot = (wib - 4u) & 7u;
     const uint32_t w0 = b * kWorldsPerBlock + b_slot * kWorldsPerWave;
@@ -1607,7 +1789,11 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
                 for (uint32_t first = 0; first < G; first += kWave * 8u)
                     prev_all += mrl::read_counts<8>(before_step, first, G, epoch - 1u, 0u, &unused, timed_out);
             RSTAMP(0, 8);
+#ifdef MRL_HANABI_ROLLOUT_LATE_COUNT  // measurement variant: the counts leave when phase A is through, as until round 4
             flag_wait(&s_a_done, 4u * (k + 1u));
+#else
+            flag_wait(&s_a_moved, 4u * (k + 1u));  // the transition is through (the encode is not): the counts can travel meanwhile
+#endif
             RSTAMP(0, 9);
             uint32_t start_of[kWavesPerBlock + 1];
             start_of[0] = 0;
@@ -1623,6 +1809,7 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
             }
             base += prev_all;  // previous step's finished worlds, all workgroups (0 in the first step)
             RSTAMP(0, 10);
+            flag_wait(&s_a_done, 4u * (k + 1u));  // the phase-A waves have written their last bit vector: the finished worlds' slots are free
             deal_finished_worlds<kV>(p, [&](uint32_t wv) { return rollout_lds(smem, wv, buf); }, s_fin[buf], start_of, base + lower, lane);
             flag_raise(&s_dealt, lane);
             RSTAMP(0, 11);
@@ -1658,20 +1845,13 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
             const WaveLds ls = rollout_lds(smem, slot, buf);
             p.sample_step = first_step + k;
             bool over = false, next_is_1 = false;
+            Moved m{false, 0.f};
+            uint8_t *rec = ls.rec + idx * kRecStride;
+            const uint32_t world = a_w0 + idx;
             if (idx < a_nw) {
-                uint8_t *rec = ls.rec + idx * kRecStride;
-                const uint32_t world = a_w0 + idx;
-                const Moved m = move_world<kV>(p, rec, world, 0, 0, true);
-                const uint32_t next = rec[R_CUR] & 1u;
-                next_is_1 = next != 0;
-                encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                m = move_world<kV>(p, rec, world, 0, 0, true);
                 over = m.over;
-                const uint32_t mover = over ? 0u : next;  // (a new game opens with agent 0: one writer per ACTIVE word)
-                p.active[(size_t)mover * N + world] = 1;
-                p.active[(size_t)(mover ^ 1u) * N + world] = 0;
-                p.reward[world] = m.reward;
-                p.reward[(size_t)N + world] = m.reward;
-                p.done[world] = over ? 1 : 0;
+                next_is_1 = (rec[R_CUR] & 1u) != 0;
             }
             const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
             const uint32_t my_overs = (uint32_t)(half ? all_overs >> 32 : all_overs), my_movers = (uint32_t)(half ? all_movers >> 32 : all_movers);
@@ -1680,6 +1860,17 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
                 s_counts[buf][slot] = (uint32_t)__popc(my_overs);
                 s_overs[buf][slot] = my_overs;
                 s_movers[buf][slot] = my_movers;
+            }
+            flag_raise(&s_a_moved, lane);  // the scan wave publishes and looks back while this wave encodes (as in the single step)
+            if (idx < a_nw) {
+                const uint32_t next = next_is_1 ? 1u : 0u;
+                encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                const uint32_t mover = over ? 0u : next;  // (a new game opens with agent 0: one writer per ACTIVE word)
+                p.active[(size_t)mover * N + world] = 1;
+                p.active[(size_t)(mover ^ 1u) * N + world] = 0;
+                p.reward[world] = m.reward;
+                p.reward[(size_t)N + world] = m.reward;
+                p.done[world] = over ? 1 : 0;
             }
             flag_raise(&s_a_done, lane);
             RSTAMP(wib, 3);
@@ -1696,7 +1887,7 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
         flag_wait(&s_a_done, 4u * (k + 1u));
         RSTAMP(b_slot, 5);
         const uint32_t overs = s_overs[buf][b_slot];
-        expand_movers(p, l, nw, overs, s_movers[buf][b_slot], out, lane);
+        expand_movers<kV>(p, l, nw, overs, s_movers[buf][b_slot], out, lane);
         RSTAMP(b_slot, 6);
         if (overs != 0) {
             flag_wait(&s_dealt, k + 1u);

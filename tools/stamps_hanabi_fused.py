@@ -27,8 +27,12 @@ def row(name, v):
     print(f"{name:>34s}  {np.percentile(v,10):6.2f} {np.median(v):6.2f} {np.percentile(v,90):6.2f} {v.max():6.2f}")
 for k, name in names.items():
     row(name, st[:, :, k] - t0)
+    if k == 1:
+        row("leaders: transition done", st[:, :4, 4] - t0)
+        row("leaders: encode done", st[:, :4, 2] - t0)
+        row("partners: first lines issued", st[:, 4:, 4] - t0)
 scan = st[:, 0, 8:11] - t0  # the scan wave's stamps
-row("scan wave: past the barrier", scan[:, 0])
+row("scan wave: counts handed over", scan[:, 0])
 row("scan wave: prefix known, visible", scan[:, 1])
 row("scan wave: re-deal done (end)", scan[:, 2])
 end = st[:, :, 6] - t0
