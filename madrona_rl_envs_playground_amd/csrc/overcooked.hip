@@ -777,16 +777,34 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
     const uint4 *src = reinterpret_cast<const uint4 *>(from + head);
     const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(gobs + head, 0, (int)(body << 4), 0x00020000);
     // (reads past the body stay inside the workgroup's LDS or return zero; their stores are dropped by the bounds check)
-    uint32_t k0 = lane;
-    for (; k0 + 3 * kWave < body + lane; k0 += 4 * kWave) {
-        const uint32_t ka = k0, kb = k0 + kWave, kc = k0 + 2 * kWave, kd = k0 + 3 * kWave;
+    // A store instruction covers 64 consecutive chunks = 1 KB.  Where a group's slab does not start on a 128-byte line
+    // (coordination_ring / forced_coordination: 5200-byte groups, asymmetric_advantages 9360), rounds counted from the slab's
+    // first chunk would make EVERY instruction straddle nine lines, two of them partial -- and a line's two parts are two
+    // write-through transactions, which is what the drain is made of (section 4.1 of DESIGN.md).  So the rounds are counted
+    // from the line boundary in front of the slab: the first `lshift` lanes of round 0 fall in front of it (their offset
+    // wraps, the descriptor drops them; their LDS read lands in the wave's own region), every other instruction is eight
+    // whole lines, and only the slab's first and last line are shared with the neighbouring groups.
+    // Same box, us per launch with / without (profiles/r04_ae_overcooked_line_rounds_ab.txt): coordination_ring 10.14-10.17 / 10.49-10.50,
+    // forced_coordination 10.47 / 10.67, asymmetric_advantages 15.63-15.69 / 15.75-15.80; the aligned layouts are untouched (lshift = 0).
+    // Not in the multi-step launches: their ordinary stores meet in the L2 anyway, and the extra round cost them 0.1 us per step.
+#ifndef MRL_NO_LINE_ROUNDS
+    const uint32_t lshift = kRestore ? 0u : (uint32_t)(reinterpret_cast<uintptr_t>(gobs + head) >> 4) & 7u;
+#else
+    const uint32_t lshift = 0u;
+#endif
+    int32_t b0 = -(int32_t)lshift;  // wave-uniform
+    for (; b0 + 3 * kWave < (int32_t)body; b0 += 4 * kWave) {
+        const uint32_t ka = (uint32_t)(b0 + (int32_t)lane), kb = ka + kWave, kc = ka + 2 * kWave, kd = ka + 3 * kWave;
         const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
         stream_store_rsrc<kPlain>(out, ka << 4, va);
         stream_store_rsrc<kPlain>(out, kb << 4, vb);
         stream_store_rsrc<kPlain>(out, kc << 4, vc);
         stream_store_rsrc<kPlain>(out, kd << 4, vd);
     }
-    for (; k0 < body + lane; k0 += kWave) stream_store_rsrc<kPlain>(out, k0 << 4, src[k0]);
+    for (; b0 < (int32_t)body; b0 += kWave) {
+        const uint32_t k = (uint32_t)(b0 + (int32_t)lane);
+        stream_store_rsrc<kPlain>(out, k << 4, src[k]);
+    }
     const uint32_t done_bytes = head + (body << 4);
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = from[done_bytes + lane];
     if constexpr (kRestore) {
