@@ -382,19 +382,23 @@ struct EarlyLineFlag {  // raises a flag in LDS behind the words (LDS operations
     static constexpr bool kActive = true;
     uint32_t *flag;
     uint32_t lane;
+#ifdef MRL_DIAG
+    unsigned long long *stamps;  // the wave's 16 stamp slots (diagnostic build): 10 + stage = when the stage was handed over
+#endif
     __device__ __forceinline__ void operator()(uint32_t stage) const
     {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(flag, stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MRL_DIAG
+        if (stamps && lane == 0) stamps[10 + stage] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 };
 template <bool kFresh, typename EarlyLine = NoEarlyLine>
-__device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t *enc, uint32_t agent, const EarlyLine &early = EarlyLine())
+__device__ __forceinline__ void encode_record_full_t(const uint32_t (&r)[kRecordWords], uint32_t *enc, uint32_t agent, const EarlyLine &early = EarlyLine())
 {
+    // (r: the record's 44 words; words 0..11 -- the deck's cards -- and 43 -- the generator -- are not looked at)
     using namespace full_game;
-    uint32_t r[kRecordWords];
-#pragma unroll
-    for (int w = 0; w < kRecordWords; w++) r[w] = reinterpret_cast<const uint32_t *>(rec)[w];
     // hands: own = the encoded agent's, other = the partner's (9 words each)
     uint32_t own[9], other[9];
 #pragma unroll
@@ -537,6 +541,14 @@ __device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t
     enc[26] = excess;
 }
 
+template <bool kFresh, typename EarlyLine = NoEarlyLine>
+__device__ __forceinline__ void encode_agent_full_t(const uint8_t *rec, uint32_t *enc, uint32_t agent, const EarlyLine &early = EarlyLine())
+{
+    uint32_t r[kRecordWords];
+#pragma unroll
+    for (int w = 0; w < kRecordWords; w++) r[w] = reinterpret_cast<const uint32_t *>(rec)[w];
+    encode_record_full_t<kFresh, EarlyLine>(r, enc, agent, early);
+}
 __device__ void encode_agent_full(const uint8_t *rec, uint32_t *enc, uint32_t agent) { encode_agent_full_t<false>(rec, enc, agent); }
 __device__ void encode_fresh_full(const uint8_t *rec, uint32_t *enc, uint32_t agent) { encode_agent_full_t<true>(rec, enc, agent); }
 
@@ -870,6 +882,234 @@ __device__ __forceinline__ Moved move_world(const HanabiParams &p, uint8_t *rec,
     Moved m;
     m.reward = (float)(int8_t)(score - old_score);
     m.over = rec[R_LIFE] < 1 || (uint32_t)(int8_t)score >= p.colors * (kR ? (uint32_t)kR : p.ranks) || (int8_t)rec[R_TURNS] <= 0;
+    return m;
+}
+
+// move_world for the full game with the record in REGISTERS (the single-launch step and the persistent rollout, whose phase A is
+// one wave per SIMD issuing ~2 400 instructions with nobody to hide a stall behind: there every scalar instruction and every
+// LDS round trip counts like a vector instruction -- the transition above compiles to 590 VALU + 300 SALU instructions, 37
+// branches around conditional LDS updates, scalar loops over the colours and 27 waits on LDS).  Words 12..43 of the record
+// are read once; the mover's legal moves (device-side policy), the action, score and termination are worked out on them
+// without a branch; the draw's two deck bytes -- the only accesses by a computed index -- are asked for up front; every
+// word a move can change goes back with unconditional stores; and the words stay in r[] for the encoder, which does not
+// read the record again.  Same arithmetic, expression by expression, as apply_action_full / draw / move_world: the two-launch
+// kernels and the healing recount keep those, and tests/ compare the two paths on every tensor and the whole record.
+struct MovedFull {
+    bool over;
+    float reward;
+    uint32_t next;  // the player to move after this step
+};
+template <bool kKeepWords>
+__device__ __forceinline__ MovedFull move_world_full(const HanabiParams &p, uint8_t *rec, uint32_t world, int32_t act0, int32_t act1, bool publish,
+                                                     uint32_t (&r)[kRecordWords])
+{
+    constexpr uint32_t kRk = 5, kAll = (1u << 25) - 1u;
+    uint32_t *rec32 = reinterpret_cast<uint32_t *>(rec);
+#pragma unroll
+    for (int w = 0; w < 12; w++) r[w] = 0u;  // the deck's cards: only ever touched in LDS, by index
+    // (kKeepWords false -- the caller's encoder reads the record again, the persistent rollout: the discard piles stay in LDS, or
+    // that kernel's thirteen waves at 128 registers spill)
+#pragma unroll
+    for (int w = 12; w < kRecordWords; w++) r[w] = (kKeepWords || w == 12 || w > 18) ? rec32[w] : 0u;
+    const uint32_t w19 = r[19], w20 = r[20], w21 = r[21];
+    const uint32_t deck_size = (r[12] >> 16) & 0xFFu;
+    const uint32_t actor = (w20 >> 24) & 1u;
+    // the draw a play or discard will make (draw(), sim.cpp:45-52): its position depends on the generator and the deck size alone
+    const uint32_t g_new = 1664525u * r[43] + 1013904223u;
+    const float unit = (float)(g_new & 0x00FFFFFFu) / (float)0x01000000;
+    const uint32_t at = (uint32_t)(int32_t)((float)deck_size * unit);  // 0 for an empty deck
+    const uint32_t drawn_card = rec[R_DECK + at], last_card = rec[R_DECK + max(deck_size, 1u) - 1u];
+
+    uint32_t a[9], q[9];  // the mover's hand, the partner's
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        const uint32_t h0 = r[R_HAND / 4 + w], h1 = r[(R_HAND + HAND_BYTES) / 4 + w];
+        a[w] = actor ? h1 : h0;
+        q[w] = actor ? h0 : h1;
+    }
+    auto hbyte = [](const uint32_t (&h)[9], uint32_t b) { return (h[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu; };
+    uint32_t info = (w20 >> 8) & 0xFFu, life = (w20 >> 16) & 0xFFu;
+    uint32_t size_a = hbyte(a, H_SIZE);
+
+    uint32_t uid = (uint32_t)(actor ? act1 : act0);
+    if (p.sample) {  // (wave-uniform) uniform over the mover's legal moves: generateActionMask (sim.cpp:381-444) on the registers
+        uint32_t legal = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kHand; i++) {
+            legal |= ((i < size_a) & (info < 8u)) ? 1u << i : 0u;
+            legal |= i < size_a ? 1u << (kHand + i) : 0u;
+        }
+        uint32_t hints = 0;
+#pragma unroll
+        for (uint32_t n = 0; n < kHand; n++) {  // all five slots, whatever the hand size (:416-417)
+            const uint32_t cardv = hbyte(q, H_CARDS + n);
+            const uint32_t col = (cardv * 205u) >> 10, rk = cardv - col * kRk;
+            hints |= col < 5u ? 1u << (2 * kHand + col) : 0u;
+            hints |= 1u << (2 * kHand + 5u + rk);
+        }
+        legal |= info > 0 ? hints : 0u;
+        legal &= 0xFFFFFu;
+        const uint32_t count = (uint32_t)__popc(legal);
+        const uint32_t pick = mrl::nth_set_bit(legal, mrl::scale(mrl::policy_hash(p.sample_seed, p.sample_step, world, actor), count));
+        uid = count ? pick : 0u;
+        if (publish) p.action_out[(size_t)actor * p.num_worlds + world] = (int32_t)uid;
+    }
+
+    // ---- apply_action_full, statement by statement, on registers ----
+    uint32_t turns = w21 & 0xFFu;
+    turns = deck_size == 0 ? (turns - 1u) & 0xFFu : turns;
+    const unsigned long long fw = (unsigned long long)w19 | ((unsigned long long)(w20 & 0xFFu) << 32);
+    const bool is_card = uid < 2 * kHand;
+    // (operands first, then selects, and & | on flags instead of && ||: written as lazy expressions these become branches around
+    // a handful of instructions each, and a branch is three or four scalar instructions that a lone wave issues one by one)
+    const bool play = is_card & (uid >= kHand);
+    const uint32_t slot_play = uid - kHand;
+    const uint32_t slot = is_card ? (play ? slot_play : uid) : 0u;
+    uint32_t card_of[kHand], kc_of[kHand], kk_of[kHand], pl_of[kHand];
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        card_of[i] = hbyte(a, H_CARDS + i);
+        kc_of[i] = hbyte(a, H_KCOLOR + i);
+        kk_of[i] = hbyte(a, H_KRANK + i);
+        pl_of[i] = a[4 + i];
+    }
+    uint32_t chosen = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) chosen = slot == i ? card_of[i] : chosen;
+    const uint32_t card = min(chosen, 24u);
+    const uint32_t col = (card * 205u) >> 10, rk = card - col * kRk;
+    const uint32_t top = (uint32_t)(fw >> (8u * col)) & 0xFFu;
+    const bool success = play & (top == rk);
+    const bool completed = success & (top + 1u == kRk);
+    {
+        // rec[R_DISCARD + card]++ for a discard or a failed play: a byte of words 12..18
+        const uint32_t b = (uint32_t)R_DISCARD + card, wi = b >> 2;
+        const uint32_t one = 1u << ((b & 3u) * 8u);
+        const uint32_t inc = (is_card & !success) ? one : 0u;
+        if constexpr (kKeepWords) {
+#pragma unroll
+            for (uint32_t w = 12; w <= 18; w++) r[w] += wi == w ? inc : 0u;
+        } else {
+            __hip_atomic_fetch_add(rec32 + wi, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (no result: ds_add_u32, no round trip)
+        }
+    }
+    info += (is_card & !play) ? 1u : 0u;
+    info += completed ? 1u : 0u;
+    life -= (play & !success) ? 1u : 0u;
+    const unsigned long long fw_step = 1ull << (8u * col);
+    const unsigned long long fw_new = fw + (success ? fw_step : 0ull);
+    // removeFromHand (:567-594): shift left when the deck is empty, else the drawn card into the slot
+    const bool shifts = is_card & (deck_size == 0), draws = is_card & (deck_size != 0);
+#pragma unroll
+    for (uint32_t i = 0; i + 1 < kHand; i++) {
+        const bool take_next = shifts & (i >= slot) & (i + 1 < size_a);
+        card_of[i] = take_next ? card_of[i + 1] : card_of[i];
+        kc_of[i] = take_next ? kc_of[i + 1] : kc_of[i];
+        kk_of[i] = take_next ? kk_of[i + 1] : kk_of[i];
+        pl_of[i] = take_next ? pl_of[i + 1] : pl_of[i];
+    }
+    const uint32_t size_less = (size_a - 1u) & 0xFFu;
+    size_a = shifts ? size_less : size_a;
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        const bool here = draws & (i == slot);
+        card_of[i] = here ? drawn_card : card_of[i];
+        kc_of[i] = here ? 0xFFu : kc_of[i];
+        kk_of[i] = here ? 0xFFu : kk_of[i];
+        pl_of[i] = here ? kAll : pl_of[i];
+    }
+    // hints (:695-788)
+    const bool hint_move = !is_card;
+    const uint32_t u = uid - 2 * kHand;
+    const bool by_color = u < 5u;
+    const uint32_t u_rank = u - 5u;
+    const uint32_t val_rank = u_rank - ((u_rank * 205u) >> 10) * kRk;  // (uid - K) % R
+    const uint32_t val = by_color ? u : val_rank;
+    const uint32_t hint_color = 0x1Fu << ((kRk * val) & 31u), hint_rank = 0x108421u << (val & 31u);  // the 5 cards of a colour / of a rank
+    const uint32_t hint = by_color ? hint_color : hint_rank;
+    const uint32_t psize = min(hbyte(q, H_SIZE), (uint32_t)kHand);
+    uint32_t reveal = 0, newly = 0;
+    uint32_t qkc[kHand], qkk[kHand], qpl[kHand];
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        const uint32_t c = hbyte(q, H_CARDS + i);
+        const uint32_t ccol = (c * 205u) >> 10, crk = c - ccol * kRk;
+        qkc[i] = hbyte(q, H_KCOLOR + i);
+        qkk[i] = hbyte(q, H_KRANK + i);
+        qpl[i] = q[4 + i];
+        const bool live = hint_move & (i < psize);
+        const bool same_color = ccol == val, same_rank = crk == val;
+        const bool match = live & (by_color ? same_color : same_rank);
+        reveal |= match ? 1u << i : 0u;
+        newly |= (match & (qkc[i] == 0xFFu)) ? 1u << i : 0u;  // sim.cpp:776 tests known_color for rank hints too
+        const uint32_t kept = qpl[i] & hint, struck = qpl[i] & ~hint;
+        qpl[i] = live ? (match ? kept : struck) : qpl[i];
+        qkc[i] = (match & by_color) ? val : qkc[i];
+        qkk[i] = (match & !by_color) ? val : qkk[i];
+    }
+    info -= hint_move ? 1u : 0u;
+
+    // checkDone's score / reward / termination (sim.cpp:812-850)
+    const uint32_t life8 = life & 0xFFu;
+    const int32_t old_score = (int8_t)((w21 >> 8) & 0xFFu);
+    const int32_t fireworks = (int32_t)(__builtin_amdgcn_sad_u8((uint32_t)fw_new, 0u, 0u) + ((uint32_t)(fw_new >> 32) & 0xFFu));
+    const int32_t score = life8 > 0 ? fireworks : 0;
+    MovedFull m;
+    m.reward = (float)(int8_t)(score - old_score);
+    m.over = (life8 < 1) | ((uint32_t)(int8_t)score >= 25u) | ((int8_t)turns <= 0);
+    m.next = actor ^ 1u;
+
+    // ---- the record's words after the move ----
+    const uint32_t lm_move = is_card ? (play ? (uint32_t)MV_PLAY : (uint32_t)MV_DISCARD) : (by_color ? (uint32_t)MV_REVEAL_COLOR : (uint32_t)MV_REVEAL_RANK);
+    const uint32_t lm_color = is_card ? col : (by_color ? val : 0xFFu);
+    const uint32_t lm_rank = is_card ? rk : (by_color ? 0xFFu : val);
+    const uint32_t deck_less = deck_size - 1u;
+    r[12] = (r[12] & 0xFF00FFFFu) | (((draws ? deck_less : deck_size) & 0xFFu) << 16);
+    r[19] = (uint32_t)fw_new;
+    r[20] = (uint32_t)(fw_new >> 32) | ((info & 0xFFu) << 8) | (life8 << 16) | ((actor ^ 1u) << 24);
+    r[21] = turns | (((uint32_t)score & 0xFFu) << 8) | (((uint32_t)(score - old_score) & 0xFFu) << 16) | (lm_move << 24);
+    r[22] = actor | ((hint_move ? (actor ^ 1u) : 0xFFu) << 8) | ((is_card ? slot : 0xFFu) << 16) | ((success ? 1u : 0u) << 24);
+    r[23] = (completed ? 1u : 0u) | (lm_color << 8) | (lm_rank << 16) | (reveal << 24);
+    r[24] = newly | (0xFFu << 8) | (r[24] & 0xFFFF0000u);
+    r[43] = draws ? g_new : r[43];
+    uint32_t an[9], qn[9];  // the two hands after the move: one of them changed
+    an[0] = card_of[0] | (card_of[1] << 8) | (card_of[2] << 16) | (card_of[3] << 24);
+    an[1] = card_of[4] | (size_a << 8) | (kc_of[0] << 16) | (kc_of[1] << 24);
+    an[2] = kc_of[2] | (kc_of[3] << 8) | (kc_of[4] << 16) | (kk_of[0] << 24);
+    an[3] = kk_of[1] | (kk_of[2] << 8) | (kk_of[3] << 16) | (kk_of[4] << 24);
+    qn[0] = q[0];
+    qn[1] = (q[1] & 0x0000FFFFu) | (qkc[0] << 16) | (qkc[1] << 24);
+    qn[2] = qkc[2] | (qkc[3] << 8) | (qkc[4] << 16) | (qkk[0] << 24);
+    qn[3] = qkk[1] | (qkk[2] << 8) | (qkk[3] << 16) | (qkk[4] << 24);
+#pragma unroll
+    for (uint32_t i = 0; i < kHand; i++) {
+        an[4 + i] = pl_of[i];
+        qn[4 + i] = qpl[i];
+    }
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        an[w] = is_card ? an[w] : a[w];
+        qn[w] = is_card ? q[w] : qn[w];
+        r[R_HAND / 4 + w] = actor ? qn[w] : an[w];
+        r[(R_HAND + HAND_BYTES) / 4 + w] = actor ? an[w] : qn[w];
+    }
+    // ---- back to LDS, without a branch: every word a move can change (the hand that changed: one of the two) ----
+    if constexpr (kKeepWords) {
+        *reinterpret_cast<uint16_t *>(rec + R_DECK_SIZE) = (uint16_t)(r[12] >> 16);  // deck size, discard[0] (the deck's last two cards share the word)
+#pragma unroll
+        for (int w = 13; w <= 18; w++) rec32[w] = r[w];
+    } else {
+        rec[R_DECK_SIZE] = (uint8_t)(r[12] >> 16);
+    }
+#pragma unroll
+    for (int w = 19; w <= 24; w++) rec32[w] = r[w];
+    {
+        uint32_t *changed = rec32 + (R_HAND + HAND_BYTES * (is_card ? actor : actor ^ 1u)) / 4;
+#pragma unroll
+        for (int w = 0; w < 9; w++) changed[w] = is_card ? an[w] : qn[w];
+    }
+    rec32[R_RNG / 4] = r[43];
+    rec[R_DECK + at] = (uint8_t)(draws ? last_card : drawn_card);  // (no draw: the byte as it was)
     return m;
 }
 
@@ -1473,6 +1713,13 @@ constexpr int kFusedBlock = kBlock + kWave;
 #ifndef MRL_HANABI_EARLY_LINE
 #define MRL_HANABI_EARLY_LINE 2
 #endif
+// 1: the full game's phase A steps and encodes on registers (move_world_full); 0: move_world + the encoder's own read of the record.
+// One box, 65536 worlds, us per step 1 / 0: single launch 15.98-16.05 / 17.01-17.07, rollout 9.11-9.21 / 9.29-9.30
+// (profiles/r04_ag_hanabi_register_transition_ab.txt); the transition's instruction stream went from 590 VALU + 300 SALU + 37 branches + 27 waits
+// on LDS to 630 + 95 + 5 + 5.
+#ifndef MRL_HANABI_REG_TRANSITION
+#define MRL_HANABI_REG_TRANSITION 1
+#endif
 
 // (nine waves = three on one of the four SIMDs: amdgpu_waves_per_eu(3) holds the kernel to 168 VGPRs)
 template <int kV>
@@ -1602,10 +1849,18 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
         Moved m{false, 0.f};
         uint8_t *rec = ls.rec + idx * kRecStride;
         const uint32_t world = a_w0 + idx;
+        constexpr bool kOnRegisters = kV == 2 && MRL_HANABI_REG_TRANSITION;
+        uint32_t r[kOnRegisters ? kRecordWords : 1];  // the record's words after the move, for the encoder
         if (idx < a_nw) {
-            m = move_world<kV>(p, rec, world, act0, act1, true);
+            if constexpr (kOnRegisters) {
+                const MovedFull mf = move_world_full<true>(p, rec, world, act0, act1, true, r);
+                m = Moved{mf.over, mf.reward};
+                next_is_1 = mf.next != 0;
+            } else {
+                m = move_world<kV>(p, rec, world, act0, act1, true);
+                next_is_1 = (rec[R_CUR] & 1u) != 0;
+            }
             over = m.over;
-            next_is_1 = (rec[R_CUR] & 1u) != 0;
         }
         const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
         // the half's share of the ballots (a wave for itself: the whole ballot is its "low half", idx = lane < 32 worlds)
@@ -1624,12 +1879,20 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
                 if (paired) {
                     // the rows' first line goes to the partner as soon as its 128 bits are in LDS (lane 0 is a world whenever
                     // the wave has any; LDS operations of a wave complete in order, so the flag follows the words)
-                    encode_agent_full_t<false>(rec, ls.enc + idx * 2 * kEncWords, next, EarlyLineFlag{&s_line0[wib], lane});
+                    const EarlyLineFlag hand_over{&s_line0[wib], lane
+#ifdef MRL_DIAG
+                                                  , p.stamps ? p.stamps + (size_t)(bid * kWavesPerBlock + wib) * 16 : nullptr
+#endif
+                    };
+                    if constexpr (kOnRegisters) encode_record_full_t<false>(r, ls.enc + idx * 2 * kEncWords, next, hand_over);
+                    else encode_agent_full_t<false>(rec, ls.enc + idx * 2 * kEncWords, next, hand_over);
                 } else {
-                    encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                    if constexpr (kOnRegisters) encode_record_full_t<false>(r, ls.enc + idx * 2 * kEncWords, next);
+                    else encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
                 }
             } else {
-                encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
+                if constexpr (kOnRegisters) encode_record_full_t<false>(r, ls.enc + idx * 2 * kEncWords, next);
+                else encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
             }
             // (a finished world's next episode opens with agent 0 to move, sim.cpp:446-532: written here, so that every
             // ACTIVE word has one writer -- two waves' stores to one address are ordered by nothing short of a wait for the first)
@@ -1656,6 +1919,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
             const uint32_t l_nw = l_w0 < N ? min((uint32_t)kWorldsPerWave, N - l_w0) : 0u;
             if (l_nw != 0) {
                 flag_wait(&s_line0[lslot], 1u);
+                FSTAMP(11);
                 // (the SIMD's arbiter prefers the older wave, and the leader hardly ever stalls: without this the partner's sixteen
                 // stores were issued when the leader was through, profiles/r04_x_hanabi_fused_timeline.txt)
                 __builtin_amdgcn_s_setprio(2);
@@ -1666,6 +1930,7 @@ mrl_hanabi_step_fused(uint32_t *hot_records, const int32_t *hot_actions, uint32_
                 FSTAMP(4);
 #if MRL_HANABI_EARLY_LINE >= 2
                 flag_wait(&s_line0[lslot], 2u);  // lines 3 and 4: card knowledge
+                FSTAMP(12);
                 __builtin_amdgcn_s_setprio(2);
                 expand_lines<kV, 3u, 5u>(p, wave_lds(smem, lslot), l_nw, s_overs[lslot], s_movers[lslot],
                                          row_resource(p.rows + (size_t)l_w0 * kWorldBlock, l_nw * kWorldBlock), lane);
@@ -1848,10 +2113,18 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
             Moved m{false, 0.f};
             uint8_t *rec = ls.rec + idx * kRecStride;
             const uint32_t world = a_w0 + idx;
+            constexpr bool kOnRegisters = kV == 2 && MRL_HANABI_REG_TRANSITION;
+            uint32_t r[kOnRegisters ? kRecordWords : 1];  // the record's words after the move, for the encoder
             if (idx < a_nw) {
-                m = move_world<kV>(p, rec, world, 0, 0, true);
+                if constexpr (kOnRegisters) {
+                    const MovedFull mf = move_world_full<false>(p, rec, world, 0, 0, true, r);
+                    m = Moved{mf.over, mf.reward};
+                    next_is_1 = mf.next != 0;
+                } else {
+                    m = move_world<kV>(p, rec, world, 0, 0, true);
+                    next_is_1 = (rec[R_CUR] & 1u) != 0;
+                }
                 over = m.over;
-                next_is_1 = (rec[R_CUR] & 1u) != 0;
             }
             const unsigned long long all_overs = __ballot(over), all_movers = __ballot(next_is_1);
             const uint32_t my_overs = (uint32_t)(half ? all_overs >> 32 : all_overs), my_movers = (uint32_t)(half ? all_movers >> 32 : all_movers);
@@ -1864,6 +2137,8 @@ mrl_hanabi_rollout(const HanabiParams p0, unsigned long long *ring, uint32_t epo
             flag_raise(&s_a_moved, lane);  // the scan wave publishes and looks back while this wave encodes (as in the single step)
             if (idx < a_nw) {
                 const uint32_t next = next_is_1 ? 1u : 0u;
+                // (the encoder reads the record again here: 31 words kept across the hand-off push this kernel, thirteen waves at 128
+                // registers each, into scratch memory)
                 encode_variant<kV>(p, rec, ls.enc + idx * 2 * kEncWords, next);
                 const uint32_t mover = over ? 0u : next;  // (a new game opens with agent 0: one writer per ACTIVE word)
                 p.active[(size_t)mover * N + world] = 1;

@@ -30,7 +30,11 @@ for k, name in names.items():
     if k == 1:
         row("leaders: transition done", st[:, :4, 4] - t0)
         row("leaders: encode done", st[:, :4, 2] - t0)
+        row("leaders: line 0 handed over", st[:, :4, 11] - t0)
+        row("partners: line 0 flag seen", st[:, 4:, 11] - t0)
         row("partners: first lines issued", st[:, 4:, 4] - t0)
+        row("leaders: lines 3, 4 handed over", st[:, :4, 12] - t0)
+        row("partners: lines 3, 4 flag seen", st[:, 4:, 12] - t0)
 scan = st[:, 0, 8:11] - t0  # the scan wave's stamps
 row("scan wave: counts handed over", scan[:, 0])
 row("scan wave: prefix known, visible", scan[:, 1])
