@@ -36,7 +36,7 @@ WORKLOADS = [  # (workload name as bench.py spells it, prof_step.py arguments)
 
 def one_pass(counter, prof_args, out_dir, log):
     cmd = ["timeout", "-k", "10", "150", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
-           "python3", os.path.join(ROOT, "tools", "prof_step.py")] + prof_args + ["--steps", "30"]
+           "python3", os.path.join(ROOT, "tools", "prof_step.py")] + prof_args + ["--steps", str(STEPS)]
     env = dict(os.environ, TMPDIR="/tmp")
     proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     open(log, "w").write(proc.stdout + proc.stderr)
@@ -47,17 +47,20 @@ def one_pass(counter, prof_args, out_dir, log):
     return " ".join(done[-1].split()[4:-1]) if done else None
 
 
+STEPS = 30  # dispatches measured per pass: the last STEPS of the kernel (prof_step.py may run warm-up steps of the same kernel first)
+
+
 def per_dispatch(out_dir, counter, kernel):
-    acc = collections.defaultdict(lambda: [0.0, 0])
+    acc = collections.defaultdict(list)
     for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
-                acc[row["Kernel_Name"]][0] += float(row["Counter_Value"])
-                acc[row["Kernel_Name"]][1] += 1
+                acc[row["Kernel_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
     if not acc:
         return None, 0
-    name, (total, n) = max(acc.items(), key=lambda kv: kv[1][1])
-    return total / n, n
+    name, rows = max(acc.items(), key=lambda kv: len(kv[1]))
+    last = [v for _, v in sorted(rows)[-STEPS:]]
+    return sum(last) / len(last), len(last)
 
 
 def main():

@@ -48,13 +48,15 @@ def main():
         for i in range(args.steps):
             sim.step_with_actions(pool[i % 16])
     else:
-        sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
-                              max_information_tokens=8, max_life_tokens=3)
+        from madrona_rl_envs_playground_amd import _lib
+        with _lib.debug_knobs({"hanabi.no_persistent": 1}):  # (no cooperative launch under the profiler: rocprofv3 --pmc crashed at exit behind one)
+            sim = HanabiSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, colors=5, ranks=5, players=2,
+                                  max_information_tokens=8, max_life_tokens=3)
         mask = sim.action_mask_tensor().to_torch()
         act = sim.action_tensor().to_torch()
         # into the steady state first (games of every age, 7.8 % of the worlds finishing per step under the random policy): the
-        # first steps of 65536 fresh games finish nobody, and a finished world costs two blocks instead of one.  The persistent
-        # rollout is another kernel, so these steps are not in the step kernel's averages.
+        # first steps of 65536 fresh games finish nobody, and a finished world costs two blocks instead of one.  These are
+        # launches of the same step kernel: tools/pmc_traffic.py averages the LAST `--steps` dispatches only.
         sim.rollout_random(200, seed=1, first_step=0)
         for i in range(args.steps):
             act.copy_((torch.rand(mask.shape, device="cuda") * mask).argmax(-1, keepdim=True).to(torch.int32))
