@@ -1693,18 +1693,20 @@ __device__ __forceinline__ void flag_raise(uint32_t *flag, uint32_t lane)  // by
 
 // The whole step in ONE launch (mrl_step on one GPU, batches of one sub-block per workgroup: up to 262144 worlds):
 // transition, look-back over the lower workgroups' finished counts instead of a kernel boundary, re-deal.  Workgroup
-// b owns worlds [256 b, 256 b + 256) and has NINE waves: eight step 32 worlds each exactly like mrl_hanabi_step
-// (phase A lane = world, phase B bits -> bytes), the ninth -- the scan wave -- owns no world.  It sleeps at the barrier
-// behind phase A, then publishes the workgroup's count, looks back (recounting what does not appear,
-// episode_scan.hpp) and deals ALL of the workgroup's finished worlds anew in their slots of the other waves' LDS
-// (record + both agents' bit vectors) while the eight are streaming out their rows; each of them appends the rows
-// of its own finished worlds to its stream of stores.  The serial part of the re-deal (look-back 2 us, ten dependent
-// draws, encode) is in no stepping wave's instruction stream: measured with the re-deal in the stepping waves (the
-// last of them looking back first), that wave started its rows 2 us late and ended the workgroup in 208 of 256 cases,
-// and every wave with a finished world queued 2.8 us of re-deal behind its rows
-// (profiles/r03_e_hanabi_fused_timeline.txt).
-// The two-launch pair stays for the sharded path (the episode base comes from the other ranks in between) and for
-// larger batches.
+// b owns worlds [256 b, 256 b + 256) and has NINE waves: eight own 32 worlds each (phase A lane = world -- run by four
+// LEADERS for their own and a partner's worlds, see below -- phase B bits -> bytes), the ninth -- the scan wave -- owns no
+// world.  It waits for the leaders' counts, which they hand over behind the TRANSITION (a counter in LDS, round 4; until
+// then: a barrier behind the whole of phase A), publishes the workgroup's count, looks back (recounting what does not
+// appear, episode_scan.hpp) while the leaders encode, and deals ALL of the workgroup's finished worlds anew in their slots
+// of the other waves' LDS (record + both agents' bit vectors) while the eight are streaming out their rows; each of them
+// appends the rows of its own finished worlds to its stream of stores.  The serial part of the re-deal (look-back 2 us,
+// ten dependent draws, encode) is in no stepping wave's instruction stream: measured with the re-deal in the stepping
+// waves (the last of them looking back first), that wave started its rows 2 us late and ended the workgroup in 208 of
+// 256 cases, and every wave with a finished world queued 2.8 us of re-deal behind its rows
+// (profiles/r03_e_hanabi_fused_timeline.txt).  No workgroup barrier after the first: every hand-off inside the workgroup is
+// a counter in LDS that its writer raises whatever the other waves do, so nobody waits for more than it needs.
+// The two-launch pair stays for the RCCL form of the sharded path (the episode base comes from the other ranks in between;
+// the mailbox form runs this kernel) and for larger batches.
 constexpr int kFusedBlock = kBlock + kWave;
 // Measurement variants (same sources, other flags: tools/hanabi_ab.sh).  0: every row store waits for the whole encode; 1: the
 // rows' first line is stored by the partner wave while its leader still encodes; 2: lines 3 and 4 (card knowledge) as well.

@@ -792,18 +792,20 @@ __device__ __forceinline__ void observe_patch(const StepParams &p, const uint8_t
 #else
     const uint32_t lshift = 0u;
 #endif
+    // (signed chunk indices: a lane in front of the slab reads up to 112 bytes below the tile -- the wave's own state -- and its
+    // store offset wraps to 0xFFFFFF90 and more, which the descriptor drops)
     int32_t b0 = -(int32_t)lshift;  // wave-uniform
     for (; b0 + 3 * kWave < (int32_t)body; b0 += 4 * kWave) {
-        const uint32_t ka = (uint32_t)(b0 + (int32_t)lane), kb = ka + kWave, kc = ka + 2 * kWave, kd = ka + 3 * kWave;
+        const int32_t ka = b0 + (int32_t)lane, kb = ka + kWave, kc = ka + 2 * kWave, kd = ka + 3 * kWave;
         const uint4 va = src[ka], vb = src[kb], vc = src[kc], vd = src[kd];
-        stream_store_rsrc<kPlain>(out, ka << 4, va);
-        stream_store_rsrc<kPlain>(out, kb << 4, vb);
-        stream_store_rsrc<kPlain>(out, kc << 4, vc);
-        stream_store_rsrc<kPlain>(out, kd << 4, vd);
+        stream_store_rsrc<kPlain>(out, (uint32_t)ka << 4, va);
+        stream_store_rsrc<kPlain>(out, (uint32_t)kb << 4, vb);
+        stream_store_rsrc<kPlain>(out, (uint32_t)kc << 4, vc);
+        stream_store_rsrc<kPlain>(out, (uint32_t)kd << 4, vd);
     }
     for (; b0 < (int32_t)body; b0 += kWave) {
-        const uint32_t k = (uint32_t)(b0 + (int32_t)lane);
-        stream_store_rsrc<kPlain>(out, k << 4, src[k]);
+        const int32_t k = b0 + (int32_t)lane;
+        stream_store_rsrc<kPlain>(out, (uint32_t)k << 4, src[k]);
     }
     const uint32_t done_bytes = head + (body << 4);
     if (lane < nbytes - done_bytes) gobs[done_bytes + lane] = from[done_bytes + lane];
