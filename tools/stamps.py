@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 st = sim._tensor(14).to_torch().cpu().numpy().view(np.uint64).reshape(-1, 16).astype(np.int64)
 st = st[st[:, 0] > 0]
 names = ["start", "loaded+sync", "transition", "curmap", "dynamic list", "patch+stream", "loads issued+fills", "state in LDS", "pass3", "", "", "", "", "", "", "end"]
-cols = [k for k in (0, 6, 7, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 15) if (st[:, k] > 0).all()]
+cols = [k for k in (0, 6, 7, 1, 2, 3, 4, 5, 8, 9, 10, 11, 15) if (st[:, k] > 0).all()]  # (slot 12 holds HW_ID / XCC_ID, not a time)
 print("s_memtime deltas per wave (shader cycles; /2400 = us at 2.4 GHz), median [p10..p90] over", len(st), "waves")
 for a, b in zip(cols, cols[1:]):
     d = st[:, b] - st[:, a]
