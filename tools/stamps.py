@@ -7,9 +7,15 @@ from madrona_rl_envs_playground_amd import layouts
 from madrona_rl_envs_playground_amd import _lib
 _lib.debug_set("stamps", 1)
 from madrona_rl_envs_playground_amd.simulators import ExecMode, OvercookedSimulator
-n = 32768
-params = layouts.get_base_layout_params("cramped_room", 400)
+# usage: tools/stamps.py [layout [worlds [knob=value ...]]]   (two groups per wave: the phase stamps are the FIRST group's, "end" the wave's)
+layout = sys.argv[1] if len(sys.argv) > 1 else "cramped_room"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    _lib.debug_set(k, int(v))
+params = layouts.get_base_layout_params(layout, 400)
 sim = OvercookedSimulator(exec_mode=ExecMode.CUDA, gpu_id=0, num_worlds=n, **params)
+print(layout, n, sys.argv[3:], sim.kernel_name)
 pool = [torch.randint(0, 6, (2, n, 1), dtype=torch.int32, device="cuda") for _ in range(8)]
 for i in range(50):
     sim.step_with_actions(pool[i % 8])
