@@ -35,3 +35,8 @@ rs, re = st[:, 13] / 100.0, st[:, 14] / 100.0   # s_memrealtime: 100 MHz, common
 t0 = rs.min()
 print(f"wave starts (us after the first): p50 {np.median(rs - t0):.2f} p90 {np.percentile(rs - t0, 90):.2f} max {(rs - t0).max():.2f}")
 print(f"wave ends   (us after the first start): p10 {np.percentile(re - t0, 10):.2f} p50 {np.median(re - t0):.2f} max {(re - t0).max():.2f}")
+# by XCD (XCC_ID, upper half of slot 12): does every XCD get the same share of the fabric?
+xcc = (st[:, 12] >> 32) & 0xF
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print(f"  XCC {x}: {m.sum():5d} waves, start p50 {np.median(rs[m] - t0):5.2f}, end p50 {np.median(re[m] - t0):5.2f} p90 {np.percentile(re[m] - t0, 90):5.2f} max {(re[m] - t0).max():5.2f}")
