@@ -56,6 +56,14 @@ constexpr int kWorldsPerBlock = kWorldsPerWave * kWavesPerBlock;
 #define MRL_HANABI_EU 2
 #endif
 
+// 1: the full game's phase A steps and encodes on registers (move_world_full); 0: move_world + the encoder's own read of the record.
+// One box, 65536 worlds, us per step 1 / 0: single launch 15.98-16.05 / 17.01-17.07, rollout 9.11-9.21 / 9.29-9.30
+// (profiles/r04_ag_hanabi_register_transition_ab.txt), the two-launch pair 22.26-22.32 / 22.95-23.07 (r04_am: two waves per SIMD run phase A
+// there, so the scalar instructions it saves issue in each other's shadow); the transition's instruction stream went from
+// 590 VALU + 300 SALU + 37 branches + 27 waits on LDS to 630 + 95 + 5 + 5.
+#ifndef MRL_HANABI_REG_TRANSITION
+#define MRL_HANABI_REG_TRANSITION 1
+#endif
 constexpr int kHand = 5;
 constexpr int kRecordBytes = 176;
 constexpr int kRecordWords = kRecordBytes / 4;
@@ -1416,12 +1424,24 @@ __device__ __forceinline__ uint32_t step_body(const HanabiParams &p, uint8_t *sm
             uint32_t *enc = l.enc + lane * 2 * kEncWords;
             const uint32_t world = w0 + lane;
             Moved m{false, 0.f};
-            if (!ABLATED(1)) m = move_world<kV>(p, rec, world, act0, act1, true);
-            STAMP(2);
-            const uint32_t next = rec[R_CUR] & 1u;
+            uint32_t next;
+            if constexpr (kV == 2 && MRL_HANABI_REG_TRANSITION) {
+                // the full game's transition and encode on registers (move_world_full; the healing recount and the generic
+                // variants keep move_world, and tests/ compare variant 2 with 1 and 0 on every tensor and the record)
+                uint32_t r[kRecordWords];
+                const MovedFull mf = move_world_full<true>(p, rec, world, act0, act1, true, r);
+                STAMP(2);
+                m = Moved{mf.over, mf.reward};
+                next = mf.next;
+                encode_record_full_t<false>(r, enc, next);
+            } else {
+                if (!ABLATED(1)) m = move_world<kV>(p, rec, world, act0, act1, true);
+                STAMP(2);
+                next = rec[R_CUR] & 1u;
+                // observationSystem (:794-810): only the player to move is refreshed
+                if (!ABLATED(1)) encode_variant<kV>(p, rec, enc, next);
+            }
             next_is_1 = next != 0;
-            // observationSystem (:794-810): only the player to move is refreshed
-            if (!ABLATED(1)) encode_variant<kV>(p, rec, enc, next);
             STAMP(3);
             // (Moving these small per-world stores behind phase B -- hipcc waits on vmcnt before it reuses a
             // store's data register, 0.4..1 us here -- was measured: 36.0 us per step against 34.5.)
@@ -1714,13 +1734,6 @@ constexpr int kFusedBlock = kBlock + kWave;
 // (A waiting wave that sleeps 0.6 us before it starts polling its leader's counter changed nothing: r04_z.)
 #ifndef MRL_HANABI_EARLY_LINE
 #define MRL_HANABI_EARLY_LINE 2
-#endif
-// 1: the full game's phase A steps and encodes on registers (move_world_full); 0: move_world + the encoder's own read of the record.
-// One box, 65536 worlds, us per step 1 / 0: single launch 15.98-16.05 / 17.01-17.07, rollout 9.11-9.21 / 9.29-9.30
-// (profiles/r04_ag_hanabi_register_transition_ab.txt); the transition's instruction stream went from 590 VALU + 300 SALU + 37 branches + 27 waits
-// on LDS to 630 + 95 + 5 + 5.
-#ifndef MRL_HANABI_REG_TRANSITION
-#define MRL_HANABI_REG_TRANSITION 1
 #endif
 
 // (nine waves = three on one of the four SIMDs: amdgpu_waves_per_eu(3) holds the kernel to 168 VGPRs)
