@@ -195,15 +195,20 @@ def mappo_leg(args, torch, local_rank):
             ring = buffers["obs"]
             copies = torch.empty((8, n, env.width, env.height, 5 * env.num_players + 16), dtype=torch.int8, device="cuda")
 
-            def timed(fn, reps=200):
+            def timed(fn, reps=60, blocks=5):
+                # host-clocked and host-driven (one Python call per step): the median of a few short blocks, so that one
+                # preemption of this process does not end up in the figure (a single 200-step block once read 66 us for 11)
                 for i in range(10):
                     fn(i)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for i in range(reps):
-                    fn(i)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / reps * 1e6
+                took = []
+                for _ in range(blocks):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(reps):
+                        fn(i)
+                    torch.cuda.synchronize()
+                    took.append((time.perf_counter() - t) / reps * 1e6)
+                return sorted(took)[len(took) // 2]
             out["env_step_plus_buffer_insert_us"] = {
                 "step_into_slot": timed(lambda i: env.n_step(rand, out=ring[i % T])),
                 "step_then_clone_insert": timed(lambda i: copies[i % 8].copy_(env.n_step(rand)[0][env.ego_ind].obs))}
