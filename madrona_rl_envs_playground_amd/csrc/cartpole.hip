@@ -515,9 +515,27 @@ __global__ void __launch_bounds__(kBlock) mrl_cartpole_step_fused(uint32_t n, co
     for (int u = 0; u < kUnroll; u++) {
         const uint32_t i = first + u * kBlock + threadIdx.x;
         if (i < last) {
+            // Non-temporal stores: the 25 MB a step writes at 1 M worlds are read again by the next launch, not by this one, and
+            // what is still dirty in the L2 when the kernel ends has to be written back before the next one starts; with the
+            // hint the lines leave while the kernel runs.  Same box, us per step at 1 M worlds, five runs each: 8.9-9.5 against
+            // 9.3-9.7 with ordinary stores (profiles/r04_ap_cartpole_nt_ab.txt); write-through (sc1) stores instead: 10.9 (r04_an).
+#ifndef MRL_CARTPOLE_OUT_PLAIN
+            if (!over[u]) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 v;
+                v.x = s[u].x;
+                v.y = s[u].y;
+                v.z = s[u].z;
+                v.w = s[u].w;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(state + i));
+            }
+            __builtin_nontemporal_store(1.f, reward + i);
+            __builtin_nontemporal_store(over[u] ? 1 : 0, done + i);
+#else
             if (!over[u]) state[i] = s[u];
             reward[i] = 1.f;
             done[i] = over[u] ? 1 : 0;
+#endif
         }
     }
     CP_STAMP(6);
